@@ -1,0 +1,213 @@
+/*
+ * xq_hip.h -- C ABI of libxq_hip.so: the MI355X (gfx950) self-play hot path of
+ * wenjunyang/xiangqi-alphazero as hand-written HIP kernels.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer named dev_* / ws is DEVICE memory owned by the caller; nothing is allocated or
+ *     freed behind the caller's back.  `stream` is a hipStream_t passed as void*.
+ *   - return value: XQ_OK (0) or a negative XQ_ERR_* code; no exceptions cross the ABI; all entry
+ *     points are re-entrant (no global mutable state).  Launches are asynchronous on `stream`
+ *     unless the function says it synchronises.
+ *   - boards are the reference's layout: int8[10][9] row-major (90 bytes), red positive, black
+ *     negative, pieces 1..7 = king advisor bishop knight rook cannon pawn (training/game.py:49-65);
+ *     player/side is +1 (red) or -1 (black); an action id is (from_sq*90 + to_sq),
+ *     sq = row*9+col (training/game.py:112-121).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef XQ_HIP_H
+#define XQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XQ_OK 0
+#define XQ_ERR_ARG (-1)      /* bad argument (null pointer, non-positive size, ...) */
+#define XQ_ERR_HIP (-2)      /* a HIP runtime call / kernel launch failed; see xq_last_hip_error() */
+#define XQ_ERR_WORKSPACE (-3) /* workspace too small */
+#define XQ_ERR_OVERFLOW (-4) /* a device-side capacity was exceeded (reported by xq_engine_stats) */
+
+#define XQ_SQUARES 90
+#define XQ_ACTION_SPACE 8100
+#define XQ_STATE_FLOATS 1350  /* 15 planes x 90, training/game.py:627 */
+#define XQ_MAXM 128           /* legal moves kept per position (reference buffer: 200, observed max 69) */
+#define XQ_SAMPLE_BYTES 640
+#define XQ_RESULT_BYTES 16
+
+const char *xq_version(void);
+/* hipGetErrorString of the last failing HIP call on this thread ("" if none). */
+const char *xq_last_hip_error(void);
+
+/* =====================================================================================
+ * B1 -- rules engine plug point.  Replaces training/cython_engine/game_core.pyx:493-569
+ * (cy_generate_legal_moves, cy_is_in_check, cy_find_king, cy_is_attacked, cy_has_legal_moves)
+ * and their Python twins training/game.py:176-265, 297-521, 552-563, 618-640, batched over n boards.
+ * ===================================================================================== */
+
+/* cy_generate_legal_moves + cy_is_in_check(board, side) + cy_has_legal_moves for n boards.
+ * dev_moves[i][0..counts[i]) = action ids in the reference's emission order.
+ * dev_in_check may be NULL.  dev_status (may be NULL): per board 0, or 1 if more than XQ_MAXM
+ * legal moves / more than 256 pseudo-legal candidates were met (list truncated). */
+int xq_movegen_batch(const int8_t *dev_boards, const int8_t *dev_side, int n, uint16_t *dev_moves,
+                     uint16_t *dev_counts, uint8_t *dev_in_check, uint8_t *dev_status, void *stream);
+
+/* cy_is_attacked(board, r, c, by) for every square and both attackers:
+ * dev_out[i][0][sq] = attacked by red, dev_out[i][1][sq] = attacked by black (uint8 0/1). */
+int xq_attack_map_batch(const int8_t *dev_boards, int n, uint8_t *dev_out, void *stream);
+
+/* cy_find_king for both sides: dev_out[i][0] = red king square or -1, dev_out[i][1] = black. */
+int xq_find_king_batch(const int8_t *dev_boards, int n, int16_t *dev_out, void *stream);
+
+/* XiangqiGame.get_state_for_nn (training/game.py:618-640): dev_out[i] = float32[15][10][9]. */
+int xq_encode_batch(const int8_t *dev_boards, const int8_t *dev_side, int n, float *dev_out, void *stream);
+
+/* XiangqiGame.get_material_score (training/game.py:552-563): dev_out[i][0] red, [i][1] black. */
+int xq_material_batch(const int8_t *dev_boards, int n, int32_t *dev_out, void *stream);
+
+/* XiangqiGame.make_move on copies (training/game.py:528-550, board part): child j is
+ * dev_boards[parent[j]] with action[j] applied; side flipped.  Used for perft-style expansion. */
+int xq_apply_moves_batch(const int8_t *dev_boards, const int8_t *dev_side, const uint32_t *dev_parent,
+                         const uint16_t *dev_action, int m, int8_t *dev_out_boards, int8_t *dev_out_side,
+                         void *stream);
+
+/* XiangqiGame.is_game_over (training/game.py:565-616) for n independent game states.
+ * dev_hist[i] = the last min(12, move_count) pre-move boards (int8[12][90], oldest first, rest ignored).
+ * dev_out[i][0] = done (0/1), dev_out[i][1] = winner (+1/-1/0, or 2 when not done). */
+int xq_game_over_batch(const int8_t *dev_boards, const int8_t *dev_side, const int32_t *dev_move_count,
+                       const int32_t *dev_no_capture, const int8_t *dev_hist, int n, int8_t *dev_out,
+                       void *stream);
+
+/* =====================================================================================
+ * B3 -- self-play operator.  Replaces the search + game loop that the reference fans out over
+ * processes: training/mcts.py:21-206 (MCTSNode, MCTS.search), training/parallel_selfplay.py:42-134
+ * (_play_one_game) and the per-evaluation IPC of training/inference_server.py:37-497.
+ *
+ * One engine = n_games concurrent game slots resident on one GPU.  A *step* is
+ *     xq_engine_select   every slot advances (finishing moves/games, running simulations whose leaves are
+ *                        terminal) until it needs ONE network evaluation, and writes that position's
+ *                        15x10x9 planes into dev_nn_input[slot]
+ *     <evaluator>        B2: any batched policy/value function over dev_nn_input (the ResNet)
+ *     xq_engine_expand   consumes dev_policy[slot] / dev_value[slot]: root or leaf expansion with the
+ *                        reference's mask-and-normalise, backup along the recorded path
+ * Simulations of one game stay strictly sequential (as in mcts.py:126-153); parallelism is across games.
+ * ===================================================================================== */
+
+typedef struct xq_engine_config {
+    int32_t n_games;               /* concurrent slots G */
+    int32_t num_simulations;       /* MCTS simulations per move (TrainingConfig.num_simulations) */
+    double  c_puct;                /* 1.5 */
+    int32_t temperature_threshold; /* plies with T=1.0, then late_temperature (parallel_selfplay.py:92) */
+    int32_t max_game_length;
+    int32_t random_opening_moves;
+    int32_t enable_resign;
+    double  resign_threshold;
+    int32_t resign_check_steps;    /* <= 16 */
+    int32_t add_noise;             /* Dirichlet noise at the root (mcts.py:117-121); self-play: 1 */
+    double  dirichlet_alpha;       /* 0.3 */
+    double  noise_eps;             /* 0.25 */
+    double  late_temperature;      /* 0.3 */
+    uint64_t seed;                 /* Philox key (run seed); rank goes into the key as well */
+    int32_t rank;
+    int32_t inject_len;            /* 0: device RNG; >0: draws come from dev_inject (tests), per slot
+                                      4 streams x inject_len raw uint64 (tests/draws.py order) */
+    int64_t games_target;          /* stop starting games after this many (<=0: unlimited) */
+    int32_t max_out_samples;       /* capacity of the finished-sample ring */
+    int32_t max_out_results;       /* capacity of the game-result ring */
+    int32_t manual_moves;          /* 1: search only -- never plays the move (xq_engine_set_position +
+                                      num_simulations steps, then xq_engine_read_root); used for MCTS.search parity */
+    int32_t reserved;
+} xq_engine_config;
+
+/* Host-side handle: plain pointers into the caller's workspace.  Treat as opaque. */
+typedef struct xq_engine {
+    xq_engine_config cfg;
+    int32_t node_cap, path_cap, stage_cap, pad0;
+    void *p[32];
+} xq_engine;
+
+typedef struct xq_engine_stats {
+    uint64_t sims;            /* completed simulations (leaf evaluated or terminal) */
+    uint64_t terminal_sims;
+    uint64_t leaf_evals;      /* network evaluations consumed by simulations */
+    uint64_t root_evals;      /* network evaluations consumed by roots (incl. the resign probe) */
+    uint64_t moves_played;
+    uint64_t games_finished, red_wins, black_wins, draws;
+    uint64_t plies_finished;  /* sum of move_count over finished games */
+    uint64_t nodes_created;
+    uint64_t depth_sum;       /* sum over simulations of descent depth */
+    uint64_t children_scanned;/* sum over descents of children read by PUCT select */
+    uint64_t resigns;
+    uint64_t samples_written, samples_dropped;
+    uint64_t overflow;        /* non-zero: a device capacity was exceeded (results invalid) */
+    uint64_t games_started;
+    uint64_t reserved[14];
+} xq_engine_stats;
+
+/* Bytes of device workspace the engine needs for cfg (tree arenas dominate:
+ * n_games * (1 + (num_simulations+1)*XQ_MAXM) nodes * 24 B -- sized for 288 GB HBM, no per-node malloc). */
+size_t xq_engine_workspace_bytes(const xq_engine_config *cfg);
+
+/* Carves `ws` (>= workspace_bytes, 256-byte aligned), zeroes state, every slot starts a new game.
+ * dev_inject: uint64[n_games][4][inject_len] or NULL. */
+int xq_engine_init(xq_engine *eng, const xq_engine_config *cfg, void *ws, size_t ws_bytes,
+                   const uint64_t *dev_inject, void *stream);
+
+int xq_engine_select(const xq_engine *eng, float *dev_nn_input /* [G][15][90] */, void *stream);
+
+/* dev_policy[slot] = float32[8100]: network LOGITS (policy_is_probs = 0; softmax over all 8100 as
+ * model.py:122 does) or already-softmaxed probabilities (policy_is_probs = 1, evaluator-plugin
+ * protocol of mcts.py:157-164).  dev_value[slot] = tanh output. */
+int xq_engine_expand(const xq_engine *eng, const float *dev_policy, const float *dev_value,
+                     int policy_is_probs, void *stream);
+
+/* Synchronises `stream`, copies the counters to host. */
+int xq_engine_stats_read(const xq_engine *eng, xq_engine_stats *host_out, void *stream);
+
+/* Synchronises; copies up to max_samples finished samples (XQ_SAMPLE_BYTES each, layout xq_sample) and
+ * up to max_results game results (xq_game_result) to host buffers and resets the rings. */
+int xq_engine_drain(const xq_engine *eng, void *host_samples, int max_samples, int *n_samples,
+                    void *host_results, int max_results, int *n_results, void *stream);
+
+/* Test / serving hooks (MCTS.search for a given position, mcts.py:94-155). Synchronise. */
+int xq_engine_set_position(const xq_engine *eng, int slot, const int8_t *host_board, int side, int move_count,
+                           int no_capture, const int8_t *host_hist12 /* int8[12][90], oldest first, last
+                           min(12,move_count) valid */, const double *host_noise /* eta per legal move or NULL */,
+                           void *stream);
+/* Root children of `slot` after a search: returns n; arrays sized XQ_MAXM. prior_kind: 0 float32, 1 float64. */
+int xq_engine_read_root(const xq_engine *eng, int slot, uint16_t *actions, int32_t *visits, double *total_value,
+                        double *prior, int *prior_kind, int32_t *root_visits, int32_t *sims_done, void *stream);
+
+/* Finished training sample (compact form of the reference's (state, pi, z) tuple,
+ * parallel_selfplay.py:97-99,123-132; dense pi / planes / flip augmentation materialise on the consumer). */
+typedef struct xq_sample {
+    int8_t board[XQ_SQUARES];
+    int8_t side;        /* player to move when the sample was taken */
+    int8_t z;           /* +1 win / 0 draw / -1 loss from `side`'s view */
+    uint8_t n_moves;
+    uint8_t late_temp;  /* 0: T = 1.0, 1: T = late_temperature */
+    uint16_t ply;       /* move_count */
+    uint16_t reserved0;
+    uint32_t slot, game_seq;
+    uint8_t pad[24];
+    uint16_t actions[XQ_MAXM];
+    uint16_t visits[XQ_MAXM];
+} xq_sample;
+
+typedef struct xq_game_result {
+    uint32_t slot, game_seq;
+    int8_t winner;      /* +1 / -1 / 0 */
+    uint8_t reason;     /* 1 rules (is_game_over), 2 max_game_length adjudication, 3 resign */
+    uint16_t steps;     /* game.move_count */
+    uint16_t n_samples;
+    uint16_t reserved;
+} xq_game_result;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XQ_HIP_H */

@@ -1,0 +1,190 @@
+"""ctypes loader of libxq_hip.so (C ABI: include/xq_hip.h) plus thin torch-tensor adapters.
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this module raises.
+torch is used only for device memory and streams; every computation below runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch  # imported BEFORE the library is loaded: both must share one HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxq_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAXM = 128
+SAMPLE_BYTES = 640
+RESULT_BYTES = 16
+ACTION_SPACE = 8100
+STATE_FLOATS = 1350
+
+
+class XqError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "xq_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-j4", "-C", CSRC, "all"])
+    return LIB_PATH
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("n_games", C.c_int32), ("num_simulations", C.c_int32), ("c_puct", C.c_double),
+                ("temperature_threshold", C.c_int32), ("max_game_length", C.c_int32),
+                ("random_opening_moves", C.c_int32), ("enable_resign", C.c_int32),
+                ("resign_threshold", C.c_double), ("resign_check_steps", C.c_int32), ("add_noise", C.c_int32),
+                ("dirichlet_alpha", C.c_double), ("noise_eps", C.c_double), ("late_temperature", C.c_double),
+                ("seed", C.c_uint64), ("rank", C.c_int32), ("inject_len", C.c_int32),
+                ("games_target", C.c_int64), ("max_out_samples", C.c_int32), ("max_out_results", C.c_int32),
+                ("manual_moves", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Engine(C.Structure):
+    _fields_ = [("cfg", EngineConfig), ("node_cap", C.c_int32), ("path_cap", C.c_int32),
+                ("stage_cap", C.c_int32), ("pad0", C.c_int32), ("p", C.c_void_p * 32)]
+
+
+class EngineStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("sims", "terminal_sims", "leaf_evals", "root_evals", "moves_played", "games_finished", "red_wins",
+                 "black_wins", "draws", "plies_finished", "nodes_created", "depth_sum", "children_scanned", "resigns",
+                 "samples_written", "samples_dropped", "overflow", "games_started")] + [("reserved", C.c_uint64 * 14)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+_lib = None
+
+
+def lib():
+    """Load libxq_hip.so; raises XqError when it is absent (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XqError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback for the product path")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u64p = C.c_void_p, C.c_int, C.POINTER(C.c_uint64)
+    L.xq_version.restype = C.c_char_p
+    L.xq_last_hip_error.restype = C.c_char_p
+    L.xq_movegen_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.xq_attack_map_batch.argtypes = [vp, i32, vp, vp]
+    L.xq_find_king_batch.argtypes = [vp, i32, vp, vp]
+    L.xq_encode_batch.argtypes = [vp, vp, i32, vp, vp]
+    L.xq_material_batch.argtypes = [vp, i32, vp, vp]
+    L.xq_apply_moves_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    L.xq_game_over_batch.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    if not hasattr(L, "xq_engine_init"):   # pragma: no cover - partial build
+        _lib = L; return L  # TEMP partial build
+    L.xq_engine_workspace_bytes.argtypes = [C.POINTER(EngineConfig)]
+    L.xq_engine_workspace_bytes.restype = C.c_size_t
+    L.xq_engine_init.argtypes = [C.POINTER(Engine), C.POINTER(EngineConfig), vp, C.c_size_t, vp, vp]
+    L.xq_engine_select.argtypes = [C.POINTER(Engine), vp, vp]
+    L.xq_engine_expand.argtypes = [C.POINTER(Engine), vp, vp, i32, vp]
+    L.xq_engine_stats_read.argtypes = [C.POINTER(Engine), C.POINTER(EngineStats), vp]
+    L.xq_engine_drain.argtypes = [C.POINTER(Engine), vp, i32, C.POINTER(C.c_int), vp, i32, C.POINTER(C.c_int), vp]
+    L.xq_engine_set_position.argtypes = [C.POINTER(Engine), i32, vp, i32, i32, i32, vp, vp, vp]
+    L.xq_engine_read_root.argtypes = [C.POINTER(Engine), i32, vp, vp, vp, vp, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
+    _lib = L
+    return L
+
+
+EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map_batch", "xq_find_king_batch",
+           "xq_encode_batch", "xq_material_batch", "xq_apply_moves_batch", "xq_game_over_batch",
+           "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
+           "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root"]
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise XqError(f"{what} failed: code {rc} ({lib().xq_last_hip_error().decode()})")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _dev(t: torch.Tensor) -> int:
+    if not t.is_cuda or not t.is_contiguous():
+        raise XqError("device-resident contiguous tensor required")
+    return t.data_ptr()
+
+
+# ---- B1 adapters (tensors in, tensors out; all on the current stream) -------------------------------------
+
+def movegen(boards: torch.Tensor, side: torch.Tensor):
+    """boards int8[n,90] (or [n,10,9]), side int8[n] -> (moves u16-as-int16 [n,128], counts int16[n],
+    in_check uint8[n], status uint8[n])."""
+    n = boards.shape[0]
+    dev = boards.device
+    moves = torch.zeros((n, MAXM), dtype=torch.int16, device=dev)
+    counts = torch.zeros(n, dtype=torch.int16, device=dev)
+    chk = torch.zeros(n, dtype=torch.uint8, device=dev)
+    status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    if n:
+        check(lib().xq_movegen_batch(_dev(boards), _dev(side), n, _dev(moves), _dev(counts), _dev(chk), _dev(status),
+                                     stream_ptr(dev)), "xq_movegen_batch")
+    return moves, counts, chk, status
+
+
+def attack_map(boards: torch.Tensor) -> torch.Tensor:
+    n = boards.shape[0]
+    out = torch.zeros((n, 2, 90), dtype=torch.uint8, device=boards.device)
+    if n:
+        check(lib().xq_attack_map_batch(_dev(boards), n, _dev(out), stream_ptr(boards.device)), "xq_attack_map_batch")
+    return out
+
+
+def find_king(boards: torch.Tensor) -> torch.Tensor:
+    n = boards.shape[0]
+    out = torch.zeros((n, 2), dtype=torch.int16, device=boards.device)
+    if n:
+        check(lib().xq_find_king_batch(_dev(boards), n, _dev(out), stream_ptr(boards.device)), "xq_find_king_batch")
+    return out
+
+
+def encode(boards: torch.Tensor, side: torch.Tensor) -> torch.Tensor:
+    n = boards.shape[0]
+    out = torch.empty((n, 15, 10, 9), dtype=torch.float32, device=boards.device)
+    if n:
+        check(lib().xq_encode_batch(_dev(boards), _dev(side), n, _dev(out), stream_ptr(boards.device)), "xq_encode_batch")
+    return out
+
+
+def material(boards: torch.Tensor) -> torch.Tensor:
+    n = boards.shape[0]
+    out = torch.zeros((n, 2), dtype=torch.int32, device=boards.device)
+    if n:
+        check(lib().xq_material_batch(_dev(boards), n, _dev(out), stream_ptr(boards.device)), "xq_material_batch")
+    return out
+
+
+def apply_moves(boards, side, parent, action):
+    """parent int32[m] (indices into boards), action int16[m] (u16 ids) -> (child boards int8[m,90], side int8[m])."""
+    m = parent.shape[0]
+    ob = torch.empty((m, 90), dtype=torch.int8, device=boards.device)
+    os_ = torch.empty(m, dtype=torch.int8, device=boards.device)
+    if m:
+        check(lib().xq_apply_moves_batch(_dev(boards), _dev(side), _dev(parent), _dev(action), m, _dev(ob), _dev(os_),
+                                         stream_ptr(boards.device)), "xq_apply_moves_batch")
+    return ob, os_
+
+
+def game_over(boards, side, move_count, no_capture, hist):
+    n = boards.shape[0]
+    out = torch.zeros((n, 2), dtype=torch.int8, device=boards.device)
+    if n:
+        check(lib().xq_game_over_batch(_dev(boards), _dev(side), _dev(move_count), _dev(no_capture), _dev(hist), n,
+                                       _dev(out), stream_ptr(boards.device)), "xq_game_over_batch")
+    return out
