@@ -191,9 +191,9 @@ typedef struct xq_sample {
     uint8_t n_moves;
     uint8_t late_temp;  /* 0: T = 1.0, 1: T = late_temperature */
     uint16_t ply;       /* move_count */
-    uint16_t reserved0;
+    uint16_t reserved0, reserved1; /* explicit: no implicit padding anywhere in this struct */
     uint32_t slot, game_seq;
-    uint8_t pad[24];
+    uint8_t pad[20];
     uint16_t actions[XQ_MAXM];
     uint16_t visits[XQ_MAXM];
 } xq_sample;

@@ -1,0 +1,164 @@
+"""Device-resident self-play engine: host-side driver of the B3 entry points (include/xq_hip.h).
+
+One `SelfPlayEngine` owns G concurrent game slots on one GPU.  A step is
+
+    select (HIP)  ->  evaluator over the [G,15,10,9] leaf batch  ->  expand/backup (HIP)
+
+all enqueued on torch's current stream; no host round-trip per simulation and no IPC (the reference's
+per-evaluation socket hop, training/inference_server.py:333-349, does not exist here).  torch provides
+device memory, the stream and (optionally) the network; search, rules, sampling and bookkeeping are the
+hand-written kernels.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import hip
+
+SAMPLE_DTYPE = np.dtype([("board", np.int8, 90), ("side", np.int8), ("z", np.int8), ("n_moves", np.uint8),
+                         ("late_temp", np.uint8), ("ply", np.uint16), ("reserved0", np.uint16), ("reserved1", np.uint16), ("slot", np.uint32),
+                         ("game_seq", np.uint32), ("pad", np.uint8, 20), ("actions", np.uint16, 128),
+                         ("visits", np.uint16, 128)])
+RESULT_DTYPE = np.dtype([("slot", np.uint32), ("game_seq", np.uint32), ("winner", np.int8), ("reason", np.uint8),
+                         ("steps", np.uint16), ("n_samples", np.uint16), ("reserved", np.uint16)])
+assert SAMPLE_DTYPE.itemsize == hip.SAMPLE_BYTES and RESULT_DTYPE.itemsize == hip.RESULT_BYTES
+
+
+def make_config(n_games: int, num_simulations: int, *, c_puct: float = 1.5, temperature_threshold: int = 20,
+                max_game_length: int = 300, random_opening_moves: int = 4, enable_resign: bool = True,
+                resign_threshold: float = -0.9, resign_check_steps: int = 5, add_noise: bool = True,
+                dirichlet_alpha: float = 0.3, noise_eps: float = 0.25, late_temperature: float = 0.3,
+                seed: int = 0, rank: int = 0, inject_len: int = 0, games_target: int = 0,
+                max_out_samples: int = 0, max_out_results: int = 0, manual_moves: bool = False) -> hip.EngineConfig:
+    """Defaults are the reference's TrainingConfig (training/train.py:55-111) and hard-coded constants
+    (mcts.py:118-121, parallel_selfplay.py:92)."""
+    if max_out_samples <= 0:
+        max_out_samples = max(4096, 4 * n_games * 64)
+    if max_out_results <= 0:
+        max_out_results = max(1024, 8 * n_games)
+    return hip.EngineConfig(n_games, num_simulations, c_puct, temperature_threshold, max_game_length,
+                            random_opening_moves, int(enable_resign), resign_threshold, resign_check_steps,
+                            int(add_noise), dirichlet_alpha, noise_eps, late_temperature, seed, rank, inject_len,
+                            games_target, max_out_samples, max_out_results, int(manual_moves), 0)
+
+
+class SelfPlayEngine:
+    def __init__(self, cfg: hip.EngineConfig, device="cuda", evaluator: Optional[Callable] = None,
+                 inject: Optional[np.ndarray] = None):
+        if not torch.cuda.is_available():
+            raise hip.XqError("SelfPlayEngine needs a GPU: the HIP engine has no CPU fallback")
+        self.lib = hip.lib()
+        self.device = torch.device(device)
+        self.cfg = cfg
+        self.G = cfg.n_games
+        self.evaluator = evaluator
+        nbytes = self.lib.xq_engine_workspace_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise hip.XqError("invalid engine configuration")
+        self.workspace_bytes = int(nbytes)
+        self.ws = torch.empty(self.workspace_bytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self.ws.data_ptr() + 255) & ~255
+        self._inject = None
+        inj_ptr = None
+        if cfg.inject_len > 0:
+            inj = np.ascontiguousarray(inject, dtype=np.uint64)
+            assert inj.shape == (self.G, 4, cfg.inject_len)
+            self._inject = torch.from_numpy(inj.view(np.int64)).to(self.device)
+            inj_ptr = self._inject.data_ptr()
+        self.h = hip.Engine()
+        self.nn_input = torch.zeros((self.G, 15, 10, 9), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            hip.check(self.lib.xq_engine_init(C.byref(self.h), C.byref(cfg), base, self.workspace_bytes, inj_ptr,
+                                              hip.stream_ptr(self.device)), "xq_engine_init")
+        self.steps = 0
+
+    # ---- the three stages of a step --------------------------------------------------------------------
+    def select(self):
+        hip.check(self.lib.xq_engine_select(C.byref(self.h), self.nn_input.data_ptr(), hip.stream_ptr(self.device)),
+                  "xq_engine_select")
+        return self.nn_input
+
+    def expand(self, policy: torch.Tensor, value: torch.Tensor, is_probs: bool = False):
+        if policy.dtype != torch.float32 or value.dtype != torch.float32:
+            raise hip.XqError("policy/value must be float32")
+        policy = policy.contiguous()
+        value = value.contiguous().view(-1)
+        if policy.shape != (self.G, hip.ACTION_SPACE) or value.shape != (self.G,):
+            raise hip.XqError(f"bad evaluator output shapes {tuple(policy.shape)} {tuple(value.shape)}")
+        hip.check(self.lib.xq_engine_expand(C.byref(self.h), policy.data_ptr(), value.data_ptr(), int(is_probs),
+                                            hip.stream_ptr(self.device)), "xq_engine_expand")
+        self._keep = (policy, value)   # keep alive until the stream has consumed them
+
+    def step(self):
+        """select -> evaluator -> expand, all asynchronous on the current stream."""
+        x = self.select()
+        logits, value = self.evaluator(x)
+        self.expand(logits, value, False)
+        self.steps += 1
+
+    # ---- bookkeeping --------------------------------------------------------------------------------------
+    def stats(self, check: bool = True) -> dict:
+        s = hip.EngineStats()
+        rc = self.lib.xq_engine_stats_read(C.byref(self.h), C.byref(s), hip.stream_ptr(self.device))
+        if rc != 0 and (check or rc != -4):
+            hip.check(rc, "xq_engine_stats_read")
+        return s.as_dict()
+
+    def drain(self):
+        """-> (samples structured array, results structured array); empties the device rings."""
+        smp = np.zeros(self.cfg.max_out_samples, dtype=SAMPLE_DTYPE)
+        res = np.zeros(self.cfg.max_out_results, dtype=RESULT_DTYPE)
+        ns, nr = C.c_int(), C.c_int()
+        hip.check(self.lib.xq_engine_drain(C.byref(self.h), smp.ctypes.data, len(smp), C.byref(ns), res.ctypes.data,
+                                           len(res), C.byref(nr), hip.stream_ptr(self.device)), "xq_engine_drain")
+        return smp[:ns.value].copy(), res[:nr.value].copy()
+
+    # ---- MCTS.search for a given position (manual_moves engines; mcts.py:94-155) ---------------------------
+    def set_position(self, slot: int, board, side: int, move_count: int = 0, no_capture: int = 0, hist12=None,
+                     noise=None):
+        b = np.ascontiguousarray(board, dtype=np.int8).reshape(90)
+        h = None
+        if hist12 is not None and len(hist12):
+            h = np.zeros((12, 90), dtype=np.int8)
+            hh = np.ascontiguousarray(hist12, dtype=np.int8).reshape(-1, 90)[-12:]
+            h[:len(hh)] = hh
+        nz = None
+        if noise is not None:
+            nz = np.zeros(hip.MAXM, dtype=np.float64)
+            nz[:len(noise)] = noise
+        hip.check(self.lib.xq_engine_set_position(
+            C.byref(self.h), slot, b.ctypes.data, int(side), int(move_count), int(no_capture),
+            None if h is None else h.ctypes.data, None if nz is None else nz.ctypes.data,
+            hip.stream_ptr(self.device)), "xq_engine_set_position")
+
+    def read_root(self, slot: int) -> dict:
+        a = np.zeros(hip.MAXM, dtype=np.uint16)
+        v = np.zeros(hip.MAXM, dtype=np.int32)
+        w = np.zeros(hip.MAXM, dtype=np.float64)
+        p = np.zeros(hip.MAXM, dtype=np.float64)
+        kind, rv, sd = C.c_int(), C.c_int32(), C.c_int32()
+        n = self.lib.xq_engine_read_root(C.byref(self.h), slot, a.ctypes.data, v.ctypes.data, w.ctypes.data,
+                                         p.ctypes.data, C.byref(kind), C.byref(rv), C.byref(sd),
+                                         hip.stream_ptr(self.device))
+        if n < 0:
+            hip.check(n, "xq_engine_read_root")
+        return dict(actions=a[:n], visits=v[:n], total_value=w[:n], prior=p[:n], prior_is_f64=bool(kind.value),
+                    root_visits=rv.value, sims_done=sd.value)
+
+
+def action_probs_dense(actions: np.ndarray, visits: np.ndarray, temperature: float) -> np.ndarray:
+    """The reference's dense pi (mcts.py:190-206) from compact (action, visit) pairs, same numpy ops."""
+    pi = np.zeros(hip.ACTION_SPACE)
+    pi[actions] = visits
+    if temperature == 0:
+        best = int(actions[int(np.argmax(visits))])
+        pi = np.zeros(hip.ACTION_SPACE)
+        pi[best] = 1.0
+    elif pi.sum() > 0:
+        pi = pi ** (1.0 / temperature)
+        pi /= pi.sum()
+    return pi

@@ -84,8 +84,6 @@ def lib():
     L.xq_material_batch.argtypes = [vp, i32, vp, vp]
     L.xq_apply_moves_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.xq_game_over_batch.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
-    if not hasattr(L, "xq_engine_init"):   # pragma: no cover - partial build
-        _lib = L; return L  # TEMP partial build
     L.xq_engine_workspace_bytes.argtypes = [C.POINTER(EngineConfig)]
     L.xq_engine_workspace_bytes.restype = C.c_size_t
     L.xq_engine_init.argtypes = [C.POINTER(Engine), C.POINTER(EngineConfig), vp, C.c_size_t, vp, vp]
