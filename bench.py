@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- MCTS simulations/s of the MI355X self-play path on BASELINE.json's headline configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* = one pass of the hot path over one batch: every one of the G resident games advances by ONE network
+evaluation (k_select -> ResNet forward over [G,15,10,9] -> k_expand/backup).  Inputs (game state, trees, weights)
+are resident in HBM when the timed region starts.  Simulations are counted by the engine itself (leaf evaluations
+and terminal leaves; root evaluations are reported separately).
+
+Workload at N=1: BASELINE.json configs[2] -- 8192 concurrent games, 800 sims/move, 256ch x 10blk ResNet, fp32,
+synthetic data (games from the opening + random opening plies, counter-generated weights).  Weak scaling: every
+rank runs its own 8192 games; no collective in the data path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# FLOPs per evaluated position (2*MAC), SURVEY.md section 8a row a17
+def net_flops(c, b):
+    conv3 = 2 * 90 * 9
+    tower = conv3 * 15 * c + b * 2 * conv3 * c * c
+    heads = 2 * 90 * c * 32 + 2 * 2880 * 8100 + 2 * 90 * c * 4 + 2 * 360 * 128 + 2 * 128
+    return tower + heads, tower
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--games", type=int, default=8192)
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--evaluator", default="auto", choices=["auto", "torch", "nhwc", "hip"])
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--seed", type=int, default=2024)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from xiangqi_alphazero_amd import engine, evaluator, model, weights
+
+    net = model.XiangqiNet(args.channels, args.blocks)
+    net.load_state_dict(weights.make_state_dict(args.channels, args.blocks))
+    ev, ev_name = evaluator.make_evaluator(net, dev, args.evaluator)
+    cfg = engine.make_config(args.games, args.sims, max_game_length=400, random_opening_moves=8,
+                             temperature_threshold=20, enable_resign=True, seed=args.seed, rank=rank)  # "full" preset
+    eng = engine.SelfPlayEngine(cfg, dev, evaluator=ev)
+
+    ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(4 * args.steps)]
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.step()
+    sync()
+    s0 = eng.stats()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        e = ev_t[4 * k:4 * k + 4]
+        e[0].record()
+        x = eng.select()
+        e[1].record()
+        logits, value = ev(x)
+        e[2].record()
+        eng.expand(logits, value, False)
+        e[3].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    s1 = eng.stats()
+
+    sel_ms = sum(ev_t[4 * k].elapsed_time(ev_t[4 * k + 1]) for k in range(args.steps)) / args.steps
+    nn_ms = sum(ev_t[4 * k + 1].elapsed_time(ev_t[4 * k + 2]) for k in range(args.steps)) / args.steps
+    exp_ms = sum(ev_t[4 * k + 2].elapsed_time(ev_t[4 * k + 3]) for k in range(args.steps)) / args.steps
+
+    sims = s1["sims"] - s0["sims"]
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_sims = torch.tensor([float(sims)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_sims, op=dist.ReduceOp.SUM)
+    elapsed_max, sims_all = float(t_el.item()), float(t_sims.item())
+
+    if rank == 0:
+        flops_eval, flops_tower = net_flops(args.channels, args.blocks)
+        roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
+        if roof is None:
+            achieved = flops_eval * args.games / (nn_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "ResNet forward (%s), whole-network FLOPs / event-timed forward" % ev_name,
+                    "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4),
+                    "traffic": None}
+        d_depth = s1["depth_sum"] - s0["depth_sum"]
+        d_scan = s1["children_scanned"] - s0["children_scanned"]
+        d_nodes = s1["nodes_created"] - s0["nodes_created"]
+        out = {
+            "metric": "MCTS simulations/sec (whole node) + self-play games/hour, 256ch x 10blk ResNet",
+            "value": round(sims_all / elapsed_max, 1), "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d concurrent games per GPU, %d sims/move, %dch x %dblk ResNet"
+                       % (args.games, args.sims, args.channels, args.blocks),
+                       "games_per_gpu": args.games, "sims_per_move": args.sims, "net": "%dx%d" % (args.channels, args.blocks),
+                       "evaluator": ev_name, "parallelism": "games sharded across ranks, no data-path collective"},
+            "roofline": roof,
+            "breakdown_ms": {"select": round(sel_ms, 3), "evaluate": round(nn_ms, 3), "expand_backup": round(exp_ms, 3)},
+            "tree": {"mean_depth": round(d_depth / max(sims, 1), 3), "children_read_per_sim": round(d_scan / max(sims, 1), 2),
+                     "children_created_per_eval": round(d_nodes / max(s1["leaf_evals"] + s1["root_evals"] - s0["leaf_evals"] - s0["root_evals"], 1), 2),
+                     "root_evals": s1["root_evals"] - s0["root_evals"], "terminal_sims": s1["terminal_sims"] - s0["terminal_sims"]},
+            "games_per_hour_derived": None,
+        }
+        # games/hour cannot be observed in a few steps at 800 sims/move (one ply of all games = 801 steps); derive it
+        # from the measured simulation rate with the reference's own game-length bound (<= 200 plies, game.py:595).
+        out["games_per_hour_derived"] = {"at_200_plies": round(out["value"] * 3600 / (args.sims * 200.0), 1),
+                                         "at_100_plies": round(out["value"] * 3600 / (args.sims * 100.0), 1)}
+        if args.cpu_seconds > 0 and world == 1:
+            from oracle import cpu_baseline                      # the checker, timed beside the product path
+            cb = cpu_baseline.run(args.channels, args.blocks, budget_s=args.cpu_seconds)
+            out["cpu_baseline"] = {"value": round(cb["value"], 2), "unit": "simulations/s", "cores": cb["cores"], "kind": "port",
+                                   "sample": "%d workers x one %d-simulation search from the opening, %dx%d fp32 batch-1 predict "
+                                             "(%.1f ms), 1 thread each, %.1f s" % (cb["cores"], cb["sims_per_worker"], args.channels,
+                                                                                 args.blocks, cb["predict_ms"], cb["seconds"])}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -182,6 +182,16 @@ int xq_engine_set_position(const xq_engine *eng, int slot, const int8_t *host_bo
 int xq_engine_read_root(const xq_engine *eng, int slot, uint16_t *actions, int32_t *visits, double *total_value,
                         double *prior, int *prior_kind, int32_t *root_visits, int32_t *sims_done, void *stream);
 
+/* =====================================================================================
+ * B2 -- evaluator plug point helpers (training/model.py:20-36, 87-107 run over the leaf batch).
+ * ===================================================================================== */
+
+/* y = act(y + bias[c] (+ residual)) in place over a channels-last float32 tensor [rows][channels]
+ * (folded BatchNorm bias + ReLU + skip connection of ResBlock.forward, model.py:30-36).
+ * channels % 4 == 0, pointers 16-byte aligned; dev_residual may be NULL. */
+int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, long long rows, int channels,
+                int relu, void *stream);
+
 /* Finished training sample (compact form of the reference's (state, pi, z) tuple,
  * parallel_selfplay.py:97-99,123-132; dense pi / planes / flip augmentation materialise on the consumer). */
 typedef struct xq_sample {

@@ -1,0 +1,103 @@
+"""B2 parity: the evaluator restatement against outputs recorded from the reference XiangqiNet
+(tests/golden/nn_golden.npz, generator weights).  Tolerance 1e-5 absolute on softmax probabilities and value
+(BASELINE.json north_star), written out below."""
+import numpy as np
+import pytest
+
+import golden_io as G
+from oracle import xq_oracle as O
+
+TOL = 1e-5
+CONFIGS = [(64, 3), (128, 6), (256, 10)]
+
+
+def _states():
+    d, g = G.corpus(), G.nn_golden()
+    idx = g["corpus_index"]
+    return g, np.stack([O.encode_state(d["board"][i], int(d["side"][i])) for i in idx])
+
+
+def _check(g, tag, probs, values):
+    si = g["sample_idx"]
+    np.testing.assert_allclose(probs[:, si], g[tag + "_probs_sample"], rtol=0, atol=TOL)
+    top = g[tag + "_top_idx"]
+    np.testing.assert_allclose(np.take_along_axis(probs, top, axis=1), g[tag + "_top_prob"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(values, g[tag + "_value"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(probs.sum(axis=1), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("ch,nb", CONFIGS[:2])
+def test_model_restatement_cpu(ch, nb):
+    """Same state_dict keys/shapes as the reference; module and BN-folded inference net match its outputs."""
+    import torch
+    from xiangqi_alphazero_amd import model, weights
+    torch.set_num_threads(4)
+    g, states = _states()
+    sd = weights.make_state_dict(ch, nb)
+    net = model.XiangqiNet(ch, nb)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net.eval()
+    tag = "%dx%d" % (ch, nb)
+    pv = [net.predict(s, "cpu") for s in states]
+    _check(g, tag, np.stack([p for p, _ in pv]), np.array([v for _, v in pv]))
+    inf = model.InferenceNet(net)
+    with torch.no_grad():
+        logits, v = inf(torch.from_numpy(states))
+    _check(g, tag, torch.softmax(logits, 1).numpy(), v.numpy().reshape(-1))
+    np.testing.assert_allclose(logits.numpy()[:, g["sample_idx"]], g[tag + "_logits_sample"], rtol=0, atol=2e-5)
+
+
+def test_weight_generator_is_stable():
+    from xiangqi_alphazero_amd import weights
+    import zlib
+    sd = weights.make_state_dict_numpy(64, 3)
+    crc = 0
+    for k, v in sd.items():
+        crc = zlib.crc32(np.ascontiguousarray(v).tobytes(), crc)
+    assert crc == weights.REFERENCE_CRC_64x3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["torch", "nhwc"])
+@pytest.mark.parametrize("ch,nb", CONFIGS)
+def test_gpu_evaluators_match_reference(kind, ch, nb):
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    g, states = _states()
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(weights.make_state_dict(ch, nb))
+    ev, _ = evaluator.make_evaluator(net, "cuda", kind)
+    x = torch.from_numpy(states).cuda()
+    logits, v = ev(x)
+    probs = torch.softmax(logits, 1).cpu().numpy()
+    _check(g, "%dx%d" % (ch, nb), probs, v.cpu().numpy().reshape(-1))
+    p1, v1 = ev.predict(states[3])
+    np.testing.assert_allclose(p1, probs[3], atol=TOL)
+    # a padded, larger batch must give the same rows (no cross-sample coupling)
+    big = torch.cat([x, torch.zeros((100, 15, 10, 9), device="cuda"), x])
+    l2, v2 = ev(big)
+    np.testing.assert_allclose(l2[-len(x):].cpu().numpy(), logits.cpu().numpy(), atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_bias_act_kernel():
+    import torch
+    from xiangqi_alphazero_amd import hip
+    torch.manual_seed(0)
+    for rows, c in ((1, 4), (90 * 7, 32), (90 * 33, 256), (90 * 64 + 1, 128)):
+        y = torch.randn(rows, c, device="cuda")
+        b = torch.randn(c, device="cuda")
+        r = torch.randn(rows, c, device="cuda")
+        for res in (None, r):
+            for relu in (True, False):
+                want = y + b + (0 if res is None else res)
+                want = torch.relu(want) if relu else want
+                got = hip.bias_act_(y.clone(), b, res, relu)
+                assert torch.equal(got, want)
+    y4 = torch.randn(5, 64, 10, 9, device="cuda").contiguous(memory_format=torch.channels_last)
+    b = torch.randn(64, device="cuda")
+    want = torch.relu(y4 + b.view(1, -1, 1, 1))
+    assert torch.equal(hip.bias_act_(y4.clone(memory_format=torch.preserve_format), b), want)
+    with pytest.raises(hip.XqError):
+        hip.bias_act_(torch.randn(5, 64, 10, 9, device="cuda"), b)

@@ -1,0 +1,117 @@
+"""B2 -- evaluator plug point: batched, device-resident policy/value evaluation of the engine's leaf batch.
+
+Replaces the reference's one-position `.predict(state)` call per simulation (training/mcts.py:157-164,
+training/model.py:109-124) and its socket-batching server (training/inference_server.py:145-279) with a plain
+function over the [G,15,10,9] tensor the select kernel wrote: logits float32[G,8100] + value float32[G].
+Softmax and the legal-move mask are applied by the expand kernel, so the dense 32 KB/position probability
+vector of the reference protocol is never produced on this path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .model import InferenceNet, XiangqiNet
+
+
+class BatchedEvaluator:
+    """fp32 ResNet forward with folded BatchNorm over the whole leaf batch (optionally in micro-batches)."""
+
+    def __init__(self, net: XiangqiNet, device="cuda", micro_batch: int = 0, channels_last: bool = False):
+        self.device = torch.device(device)
+        self.net = InferenceNet(net).to(self.device).eval()
+        self.micro_batch = micro_batch
+        self.channels_last = channels_last
+        torch.backends.cuda.matmul.allow_tf32 = False
+        torch.backends.cudnn.allow_tf32 = False
+
+    def update(self, net: XiangqiNet):
+        """New weights for the next games (reference: InferenceServer.update_model, inference_server.py:476-487)."""
+        self.net.refresh(net)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        mb = self.micro_batch
+        if mb <= 0 or x.shape[0] <= mb:
+            logits, value = self.net(x)
+            return logits, value.view(-1)
+        lo, vo = [], []
+        for i in range(0, x.shape[0], mb):
+            l, v = self.net(x[i:i + mb])
+            lo.append(l); vo.append(v.view(-1))
+        return torch.cat(lo), torch.cat(vo)
+
+    # evaluator-plugin protocol of the reference, for parity tests and single-position callers
+    def predict(self, state: np.ndarray, device=None):
+        x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
+        logits, value = self(x)
+        probs = torch.softmax(logits, dim=1).squeeze(0).cpu().numpy()
+        return probs, float(value.item())
+
+
+def make_evaluator(net: XiangqiNet, device, kind: str = "auto"):
+    """-> (callable evaluator, name).  'hip': hand-written MFMA conv tower (csrc/xq_conv.hip) when the library
+    exports it; 'torch': PyTorch-ROCm ops (MIOpen/hipBLASLt); 'auto' prefers 'hip'."""
+    from . import hip
+    if kind in ("auto", "hip"):
+        try:
+            from .hip_net import HipResNetEvaluator
+            return HipResNetEvaluator(net, device), "hip-mfma-f32"
+        except (ImportError, hip.XqError):
+            if kind == "hip":
+                raise
+    if kind in ("auto", "nhwc"):
+        return ChannelsLastEvaluator(net, device), "rocm-igemm-nhwc-f32+hip-epilogue"
+    return BatchedEvaluator(net, device), "torch-rocm-f32"
+
+
+class ChannelsLastEvaluator:
+    """fp32 tower in NHWC end to end: convolutions by the ROCm library (implicit-GEMM fp32 MFMA kernels, which are
+    NHWC-native -- the NCHW eager graph spends ~8 % of a step in layout transposes around them), and ONE
+    hand-written epilogue launch per convolution (`xq_bias_act`: folded-BN bias + ReLU + skip) instead of the eager
+    graph's separate add / clamp / add kernels."""
+
+    def __init__(self, net: XiangqiNet, device="cuda"):
+        from . import hip
+        self.hip = hip
+        hip.lib()
+        self.device = torch.device(device)
+        torch.backends.cuda.matmul.allow_tf32 = False
+        torch.backends.cudnn.allow_tf32 = False
+        self.num_res_blocks = net.num_res_blocks
+        self.update(net)
+
+    def update(self, net: XiangqiNet):
+        ref = InferenceNet(net)
+        cl = lambda w: w.to(self.device).contiguous(memory_format=torch.channels_last)
+        dv = lambda t: t.to(self.device).contiguous()
+        self.w_in, self.b_in = cl(ref.w_in), dv(ref.b_in)
+        self.blocks = [(cl(getattr(ref, f"w1_{i}")), dv(getattr(ref, f"b1_{i}")),
+                        cl(getattr(ref, f"w2_{i}")), dv(getattr(ref, f"b2_{i}"))) for i in range(self.num_res_blocks)]
+        self.w_p, self.b_p = cl(ref.w_p), dv(ref.b_p)
+        self.w_v, self.b_v = cl(ref.w_v), dv(ref.b_v)
+        self.fc_p_w, self.fc_p_b = dv(ref.fc_p_w), dv(ref.fc_p_b)
+        self.fc_v1_w, self.fc_v1_b = dv(ref.fc_v1_w), dv(ref.fc_v1_b)
+        self.fc_v2_w, self.fc_v2_b = dv(ref.fc_v2_w), dv(ref.fc_v2_b)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        F = torch.nn.functional
+        ba = self.hip.bias_act_
+        h = ba(F.conv2d(x.contiguous(memory_format=torch.channels_last), self.w_in, None, padding=1), self.b_in)
+        for w1, b1, w2, b2 in self.blocks:
+            y = ba(F.conv2d(h, w1, None, padding=1), b1)
+            h = ba(F.conv2d(y, w2, None, padding=1), b2, residual=h)
+        p = ba(F.conv2d(h, self.w_p, None), self.b_p)
+        logits = F.linear(p.flatten(1), self.fc_p_w, self.fc_p_b)       # flatten(1) is logical NCHW order (model.py:71)
+        v = ba(F.conv2d(h, self.w_v, None), self.b_v)
+        v = F.relu(F.linear(v.flatten(1), self.fc_v1_w, self.fc_v1_b))
+        value = torch.tanh(F.linear(v, self.fc_v2_w, self.fc_v2_b))
+        return logits, value.view(-1)
+
+    def predict(self, state: np.ndarray, device=None):
+        x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
+        logits, value = self(x)
+        return torch.softmax(logits, dim=1).squeeze(0).cpu().numpy(), float(value.item())

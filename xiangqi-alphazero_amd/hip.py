@@ -94,6 +94,7 @@ def lib():
     L.xq_engine_set_position.argtypes = [C.POINTER(Engine), i32, vp, i32, i32, i32, vp, vp, vp]
     L.xq_engine_read_root.argtypes = [C.POINTER(Engine), i32, vp, vp, vp, vp, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
+    L.xq_bias_act.argtypes = [vp, vp, vp, C.c_longlong, i32, i32, vp]
     _lib = L
     return L
 
@@ -101,7 +102,8 @@ def lib():
 EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map_batch", "xq_find_king_batch",
            "xq_encode_batch", "xq_material_batch", "xq_apply_moves_batch", "xq_game_over_batch",
            "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
-           "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root"]
+           "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
+           "xq_bias_act"]
 
 
 def check(rc: int, what: str):
@@ -186,3 +188,22 @@ def game_over(boards, side, move_count, no_capture, hist):
         check(lib().xq_game_over_batch(_dev(boards), _dev(side), _dev(move_count), _dev(no_capture), _dev(hist), n,
                                        _dev(out), stream_ptr(boards.device)), "xq_game_over_batch")
     return out
+
+
+def bias_act_(y: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = True) -> torch.Tensor:
+    """In place on a channels-last activation: y = act(y + bias[c] (+ residual)).  `y` is a 4-d tensor whose
+    memory is NHWC-contiguous (torch.channels_last) or a 2-d [rows, C] tensor."""
+    if y.dim() == 4:
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            raise XqError("bias_act_: channels_last tensor required")
+        c = y.shape[1]
+        rows = y.numel() // c
+        if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+            raise XqError("bias_act_: channels_last residual required")
+    else:
+        rows, c = y.shape
+        if not y.is_contiguous():
+            raise XqError("bias_act_: contiguous tensor required")
+    check(lib().xq_bias_act(y.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(),
+                            rows, c, int(relu), stream_ptr(y.device)), "xq_bias_act")
+    return y

@@ -102,3 +102,7 @@ def make_state_dict(num_channels: int, num_res_blocks: int, seed: int = 0, polic
     for k, v in make_state_dict_numpy(num_channels, num_res_blocks, seed, policy_gain).items():
         sd[k] = torch.from_numpy(np.ascontiguousarray(v)) if v.shape else torch.tensor(int(v), dtype=torch.long)
     return sd
+
+
+# crc32 over make_state_dict_numpy(64, 3) in key order; pins the generator (fixtures depend on it)
+REFERENCE_CRC_64x3 = 0xE8FEBBD9
