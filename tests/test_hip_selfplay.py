@@ -1,0 +1,51 @@
+"""GPU: the B3 operator end to end behind the reference's call shape (parallel_self_play)."""
+import numpy as np
+import pytest
+
+from oracle import xq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+class QuickConfig:                       # training/train.py:645-674 ("quick" preset), shortened
+    num_simulations = 10
+    c_puct = 1.5
+    temperature_threshold = 15
+    max_game_length = 50
+    random_opening_moves = 4
+    enable_resign = True
+    resign_threshold = -0.85
+    resign_check_steps = 3
+    num_games_per_iter = 12
+
+
+def test_parallel_self_play_schema_and_rules():
+    import torch
+    from xiangqi_alphazero_amd import model, selfplay, weights
+    net = model.XiangqiNet(64, 3)
+    net.load_state_dict(weights.make_state_dict(64, 3))
+    data, stats = selfplay.parallel_self_play(net, QuickConfig(), num_workers=4, use_gpu_server=True,
+                                              gpu_device="cuda", n_slots=8, seed=5, return_compact=True)
+    for k in ("games", "red_wins", "black_wins", "draws", "avg_steps", "new_samples", "total_time", "num_workers", "mode"):
+        assert k in stats                                   # parallel_selfplay.py:316-326
+    assert stats["games"] == 12 and stats["mode"] == "hip" and stats["new_samples"] == len(data)
+    assert stats["red_wins"] + stats["black_wins"] + stats["draws"] == 12
+    smp, res = stats["compact_samples"], stats["compact_results"]
+    assert len(data) == 2 * len(smp) and len(res) == 12
+    assert sorted(int(r["game_seq"]) for r in res if r["slot"] == 0) == list(range(1, 1 + sum(res["slot"] == 0)))
+    for state, pi, z in data[:200]:
+        assert state.shape == (15, 10, 9) and state.dtype == np.float32
+        assert pi.shape == (8100,) and pi.dtype == np.float64 and abs(pi.sum() - 1.0) < 1e-12
+        assert z in (-1.0, 0.0, 1.0)
+    # originals: support of pi == legal moves of the sampled position, in any order; mirror: flipped board
+    for i in range(0, min(len(smp), 60)):
+        s = smp[i]
+        n = int(s["n_moves"])
+        np.testing.assert_array_equal(s["actions"][:n], O.legal_actions(s["board"], int(s["side"])))
+        assert int(s["visits"][:n].sum()) == QuickConfig.num_simulations
+    st0, pi0, _ = data[0]
+    st1, pi1, _ = data[1]
+    np.testing.assert_array_equal(st1, st0[:, :, ::-1])
+    assert abs(pi1.sum() - pi0.sum()) < 1e-15 and np.count_nonzero(pi1) == np.count_nonzero(pi0)
+    assert stats["avg_steps"] <= 200 and stats["simulations"] >= 12 * QuickConfig.num_simulations
+    del torch

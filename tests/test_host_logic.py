@@ -1,0 +1,120 @@
+"""CPU tests of the host side of the boundary: compact -> dense sample adapter (against the reference's recorded
+game and augmentation fixtures), and the multi-rank plumbing over gloo (world_size 2)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_io as G
+from draws import Draws
+from oracle import xq_oracle as O
+from stub_eval import StubEvaluator
+
+
+def _oracle_game_as_compact(t):
+    from xiangqi_alphazero_amd.sample_format import RESULT_DTYPE, SAMPLE_DTYPE
+    d = Draws(t["seed"])
+    ev = StubEvaluator(peaked=(t["stub"] == "peaked"))
+    samples, winner, steps, _, _ = O.play_one_game(t["cfg"], ev.predict, d.randint, d.choice_index, d.dirichlet, d.uniform)
+    arr = np.zeros(len(samples), dtype=SAMPLE_DTYPE)
+    for i, s in enumerate(samples):
+        n = len(s["actions"])
+        arr[i]["board"] = s["board"]; arr[i]["side"] = s["player"]; arr[i]["z"] = s["z"]; arr[i]["n_moves"] = n
+        arr[i]["late_temp"] = 0 if s["temperature"] == 1.0 else 1
+        arr[i]["ply"] = i; arr[i]["slot"] = 3; arr[i]["game_seq"] = 1
+        arr[i]["actions"][:n] = s["actions"]; arr[i]["visits"][:n] = s["visits"]
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    res[0]["slot"] = 3; res[0]["game_seq"] = 1; res[0]["winner"] = winner; res[0]["steps"] = steps
+    res[0]["n_samples"] = len(samples)
+    return arr, res
+
+
+def test_dense_adapter_reproduces_reference_schema_and_augmentation():
+    from xiangqi_alphazero_amd.sample_format import to_reference_tuples
+    t = G.game_traces()[0]
+    arr, res = _oracle_game_as_compact(t)
+    data, per_game = to_reference_tuples(arr, res, augment=True)
+    assert per_game == [(t["winner"], t["steps"], len(t["plies"]))] and len(data) == 2 * len(t["plies"])
+    for i, want in enumerate(t["plies"]):
+        state, pi, z = data[2 * i]
+        assert state.dtype == np.float32 and state.shape == (15, 10, 9) and pi.dtype == np.float64 and pi.shape == (8100,)
+        assert zlib.crc32(state.tobytes()) & 0xFFFFFFFF == want["state_crc"] and z == want["z"]
+        nz = np.nonzero(pi)[0]
+        assert list(nz) == want["pi"]["idx"]
+        np.testing.assert_allclose(pi[nz], [G.hexf(x) for x in want["pi"]["val"]], rtol=1e-14, atol=0)
+    # the reference's own _augment_data output for the first two samples (original, flipped, original, flipped)
+    for j, want in enumerate(t["augmented_first2"]):
+        state, pi, z = data[j]
+        assert zlib.crc32(np.ascontiguousarray(state).tobytes()) & 0xFFFFFFFF == want["state_crc"] and z == want["z"]
+        nz = np.nonzero(pi)[0]
+        assert list(nz) == want["pi"]["idx"]
+        np.testing.assert_allclose(pi[nz], [G.hexf(x) for x in want["pi"]["val"]], rtol=1e-14, atol=0)
+
+
+def test_flip_perm_matches_reference():
+    from xiangqi_alphazero_amd.sample_format import FLIP_PERM, encode_planes
+    np.testing.assert_array_equal(FLIP_PERM, G.flip_perm())
+    d = G.corpus()
+    for i in range(0, len(d["board"]), 211):
+        np.testing.assert_array_equal(encode_planes(d["board"][i], int(d["side"][i])),
+                                      O.encode_state(d["board"][i], int(d["side"][i])))
+
+
+def test_shard_games_rule():
+    from xiangqi_alphazero_amd.distributed import shard_games
+    for total, world in ((65536, 8), (50, 7), (3, 8), (20, 3)):
+        shares = [shard_games(total, world, r) for r in range(world)]
+        assert sum(shares) == total and max(shares) - min(shares) <= 1 and shares == sorted(shares, reverse=True)
+
+
+def _rank_main(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xiangqi_alphazero_amd import distributed as D, model
+    from xiangqi_alphazero_amd.sample_format import RESULT_DTYPE, SAMPLE_DTYPE
+    # weights: rank 0's values must arrive everywhere
+    torch.manual_seed(100 + rank)
+    net = model.XiangqiNet(16, 1)
+    D.broadcast_weights(net, src=0)
+    ref = model.XiangqiNet(16, 1)
+    torch.manual_seed(100)
+    ref2 = model.XiangqiNet(16, 1)
+    same = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref2.state_dict().values()))
+    # samples: ragged counts (rank 1 has none of its own results)
+    n = [5, 0][rank] if world == 2 else rank + 1
+    smp = np.zeros(n, dtype=SAMPLE_DTYPE)
+    smp["slot"] = rank; smp["ply"] = np.arange(n); smp["z"] = 1 - 2 * rank
+    res = np.zeros(2 - rank, dtype=RESULT_DTYPE)
+    res["slot"] = rank; res["winner"] = 1 - 2 * rank
+    all_s, all_r = D.all_gather_samples(smp, res, device="cpu")
+    ok = (len(all_s) == 5 and list(all_s["slot"]) == [0] * 5 and list(all_s["ply"]) == list(range(5))
+          and len(all_r) == 3 and list(all_r["slot"]) == [0, 0, 1] and list(all_r["winner"]) == [1, 1, -1])
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("%d %d" % (int(same), int(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+    del ref
+
+
+def test_two_rank_gloo_broadcast_and_gather(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / ("ok%d" % r)).read() == "1 1"
+
+
+def test_parallel_self_play_signature_matches_reference():
+    import inspect
+    from xiangqi_alphazero_amd import selfplay
+    params = list(inspect.signature(selfplay.parallel_self_play).parameters)
+    assert params[:5] == ["model", "config", "num_workers", "use_gpu_server", "gpu_device"]   # parallel_selfplay.py:264-270
+
+    class Cfg:
+        num_simulations = 8
+    with pytest.raises(AttributeError):
+        selfplay.parallel_self_play(None, Cfg())

@@ -19,12 +19,8 @@ import torch
 
 from . import hip
 
-SAMPLE_DTYPE = np.dtype([("board", np.int8, 90), ("side", np.int8), ("z", np.int8), ("n_moves", np.uint8),
-                         ("late_temp", np.uint8), ("ply", np.uint16), ("reserved0", np.uint16), ("reserved1", np.uint16), ("slot", np.uint32),
-                         ("game_seq", np.uint32), ("pad", np.uint8, 20), ("actions", np.uint16, 128),
-                         ("visits", np.uint16, 128)])
-RESULT_DTYPE = np.dtype([("slot", np.uint32), ("game_seq", np.uint32), ("winner", np.int8), ("reason", np.uint8),
-                         ("steps", np.uint16), ("n_samples", np.uint16), ("reserved", np.uint16)])
+from .sample_format import RESULT_DTYPE, SAMPLE_DTYPE, dense_pi  # noqa: E402
+
 assert SAMPLE_DTYPE.itemsize == hip.SAMPLE_BYTES and RESULT_DTYPE.itemsize == hip.RESULT_BYTES
 
 
@@ -150,15 +146,4 @@ class SelfPlayEngine:
                     root_visits=rv.value, sims_done=sd.value)
 
 
-def action_probs_dense(actions: np.ndarray, visits: np.ndarray, temperature: float) -> np.ndarray:
-    """The reference's dense pi (mcts.py:190-206) from compact (action, visit) pairs, same numpy ops."""
-    pi = np.zeros(hip.ACTION_SPACE)
-    pi[actions] = visits
-    if temperature == 0:
-        best = int(actions[int(np.argmax(visits))])
-        pi = np.zeros(hip.ACTION_SPACE)
-        pi[best] = 1.0
-    elif pi.sum() > 0:
-        pi = pi ** (1.0 / temperature)
-        pi /= pi.sum()
-    return pi
+action_probs_dense = dense_pi   # the reference's dense pi (mcts.py:190-206) from compact (action, visit) pairs
