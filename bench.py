@@ -134,6 +134,16 @@ def main():
                      "root_evals": s1["root_evals"] - s0["root_evals"], "terminal_sims": s1["terminal_sims"] - s0["terminal_sims"]},
             "games_per_hour_derived": None,
         }
+        # engine kernels against HBM: algorithmic bytes x units counted by the engine itself
+        d_evals = s1["leaf_evals"] + s1["root_evals"] - s0["leaf_evals"] - s0["root_evals"]
+        d_leaf = s1["leaf_evals"] - s0["leaf_evals"]
+        sel_bytes = 16 * d_scan + 6 * d_depth + 4 * (d_depth + sims) + 5400 * d_evals + 2 * d_nodes
+        exp_bytes = 32400 * d_evals + 24 * d_nodes + 24 * (d_depth + d_leaf)
+        out["tree_roofline"] = {
+            "k_select": {"bound": "hbm", "achieved": round(sel_bytes / args.steps / (sel_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(sel_bytes / args.steps / (sel_ms * 1e-3) / 8e12, 4)},
+            "k_expand": {"bound": "hbm", "achieved": round(exp_bytes / args.steps / (exp_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(exp_bytes / args.steps / (exp_ms * 1e-3) / 8e12, 4)}}
         # games/hour cannot be observed in a few steps at 800 sims/move (one ply of all games = 801 steps); derive it
         # from the measured simulation rate with the reference's own game-length bound (<= 200 plies, game.py:595).
         out["games_per_hour_derived"] = {"at_200_plies": round(out["value"] * 3600 / (args.sims * 200.0), 1),
