@@ -192,6 +192,17 @@ int xq_engine_read_root(const xq_engine *eng, int slot, uint16_t *actions, int32
 int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, long long rows, int channels,
                 int relu, void *stream);
 
+/* 3x3 convolution, stride 1, pad 1, C -> C channels (ResBlock.conv1/conv2 with BatchNorm folded, model.py:25-36)
+ * as fused Winograd F(2x2,3x3) on the fp32 MFMA:  y = act(conv(x) + bias (+ residual)).
+ *   dev_x, dev_y, dev_residual : float32[batch][90][channels] (NHWC; y must not alias x or residual)
+ *   dev_u : pre-transformed weights, float32[C/64][C/8][16][2][64][4] with
+ *           u[cog][chunk][4p+q][quad][co][j] = (G g G^T)[p][q] for output channel 64*cog+co and input channel
+ *           8*chunk+4*quad+j, g = the folded 3x3 filter (cross-correlation, as torch.nn.Conv2d);
+ *           xq_wino_weight_bytes(C) bytes.  channels in {64, 128, 256, 512}. */
+size_t xq_wino_weight_bytes(int channels);
+int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
+                    float *dev_y, int batch, int channels, int relu, void *stream);
+
 /* Finished training sample (compact form of the reference's (state, pi, z) tuple,
  * parallel_selfplay.py:97-99,123-132; dense pi / planes / flip augmentation materialise on the consumer). */
 typedef struct xq_sample {

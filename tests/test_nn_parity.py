@@ -101,3 +101,45 @@ def test_bias_act_kernel():
     assert torch.equal(hip.bias_act_(y4.clone(memory_format=torch.preserve_format), b), want)
     with pytest.raises(hip.XqError):
         hip.bias_act_(torch.randn(5, 64, 10, 9, device="cuda"), b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,b", [(64, 3), (64, 41), (128, 64), (256, 100), (256, 1)])
+def test_winograd_conv_kernel_vs_torch(c, b):
+    """xq_wino_conv3x3 (fp32 MFMA, fused epilogue) against torch conv2d fp32 on the same inputs."""
+    import torch
+    import torch.nn.functional as F
+    from xiangqi_alphazero_amd import hip
+    torch.backends.cudnn.allow_tf32 = False
+    g = torch.Generator(device="cpu").manual_seed(c * 1000 + b)
+    x = torch.randn(b, 90, c, generator=g).cuda()
+    w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).cuda()
+    bias = torch.randn(c, generator=g).cuda() * 0.1
+    res = torch.randn(b, 90, c, generator=g).cuda()
+    u = hip.wino_transform_weights(w)
+    x_nchw = x.view(b, 10, 9, c).permute(0, 3, 1, 2)
+    ref = F.conv2d(x_nchw.double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(b, 90, c)
+    for residual, relu in ((None, True), (res, True), (res, False)):
+        want = ref + (0 if residual is None else residual.double())
+        want = torch.relu(want) if relu else want
+        out = torch.full_like(x, float("nan"))
+        hip.wino_conv3x3(x, u, bias, out, residual, relu)
+        torch.cuda.synchronize()
+        err = (out.double() - want).abs().max().item()
+        assert err < 2e-5, (c, b, relu, err)
+    with pytest.raises(hip.XqError):
+        hip.wino_conv3x3(x, u, bias, x, None, True)          # in place is refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,nb", CONFIGS)
+def test_hip_tower_evaluator_matches_reference(ch, nb):
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    g, states = _states()
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(weights.make_state_dict(ch, nb))
+    ev, name = evaluator.make_evaluator(net, "cuda", "hip")
+    assert name.startswith("hip")
+    logits, v = ev(torch.from_numpy(states).cuda())
+    _check(g, "%dx%d" % (ch, nb), torch.softmax(logits, 1).cpu().numpy(), v.cpu().numpy().reshape(-1))

@@ -58,7 +58,7 @@ def make_evaluator(net: XiangqiNet, device, kind: str = "auto"):
     if kind in ("auto", "hip"):
         try:
             from .hip_net import HipResNetEvaluator
-            return HipResNetEvaluator(net, device), "hip-mfma-f32"
+            return HipResNetEvaluator(net, device), "hip-winograd-mfma-f32"
         except (ImportError, hip.XqError):
             if kind == "hip":
                 raise

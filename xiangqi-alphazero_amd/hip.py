@@ -95,6 +95,9 @@ def lib():
     L.xq_engine_read_root.argtypes = [C.POINTER(Engine), i32, vp, vp, vp, vp, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     L.xq_bias_act.argtypes = [vp, vp, vp, C.c_longlong, i32, i32, vp]
+    L.xq_wino_weight_bytes.argtypes = [i32]
+    L.xq_wino_weight_bytes.restype = C.c_size_t
+    L.xq_wino_conv3x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     _lib = L
     return L
 
@@ -103,7 +106,7 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_encode_batch", "xq_material_batch", "xq_apply_moves_batch", "xq_game_over_batch",
            "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
            "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
-           "xq_bias_act"]
+           "xq_bias_act", "xq_wino_weight_bytes", "xq_wino_conv3x3"]
 
 
 def check(rc: int, what: str):
@@ -207,3 +210,28 @@ def bias_act_(y: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = T
     check(lib().xq_bias_act(y.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(),
                             rows, c, int(relu), stream_ptr(y.device)), "xq_bias_act")
     return y
+
+
+def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:
+    """Folded 3x3 filters float32[C,C,3,3] -> the kernel's pre-transformed layout (see include/xq_hip.h,
+    xq_wino_conv3x3): U = G g G^T per (co, ci), computed in float64, stored float32 [C/64][C/8][16][2][64][4]."""
+    c = w.shape[0]
+    if w.shape != (c, c, 3, 3) or c % 64 or 8 % (c // 64):
+        raise XqError("wino_transform_weights: [C,C,3,3] with C in {64,128,256,512} required")
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    u = torch.einsum("pr,oirs,qs->pqoi", g, w.detach().to("cpu", torch.float64), g)      # [4,4,co,ci]
+    u = u.reshape(16, c // 64, 64, c // 8, 2, 4)                                           # xi, cog, co, chunk, quad, j
+    u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, j
+    return u.to(w.device)
+
+
+def wino_conv3x3(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, residual=None,
+                 relu: bool = True) -> torch.Tensor:
+    """x, out, residual: float32[B, 90, C] contiguous (NHWC); out must not alias x / residual."""
+    b, n, c = x.shape
+    if n != 90 or not x.is_contiguous() or not out.is_contiguous() or out.shape != x.shape:
+        raise XqError("wino_conv3x3: float32[B,90,C] contiguous tensors required")
+    check(lib().xq_wino_conv3x3(x.data_ptr(), u.data_ptr(), bias.data_ptr(),
+                                None if residual is None else residual.data_ptr(), out.data_ptr(), b, c, int(relu),
+                                stream_ptr(x.device)), "xq_wino_conv3x3")
+    return out

@@ -1,0 +1,79 @@
+"""B2 evaluator on the hand-written kernels: the residual tower (model.py:99-101; >97 % of the FLOPs at 256x10) runs
+through `xq_wino_conv3x3` -- fused Winograd F(2x2,3x3) on the fp32 MFMA with folded-BN bias, ReLU and the skip
+connection in its epilogue -- on NHWC activations that ping-pong between three preallocated buffers.  The 15->C input
+convolution (1.7 % of the FLOPs) and the two heads stay on the ROCm library via torch.  fp32 throughout.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import hip
+from .model import InferenceNet, XiangqiNet
+
+
+class HipResNetEvaluator:
+    def __init__(self, net: XiangqiNet, device="cuda"):
+        if net.num_channels % 64 or 8 % (net.num_channels // 64):
+            raise hip.XqError("HipResNetEvaluator: channels must be 64, 128, 256 or 512")
+        lib = hip.lib()
+        if not hasattr(lib, "xq_wino_conv3x3"):
+            raise hip.XqError("libxq_hip.so lacks xq_wino_conv3x3")
+        self.device = torch.device(device)
+        self.C = net.num_channels
+        self.num_res_blocks = net.num_res_blocks
+        torch.backends.cuda.matmul.allow_tf32 = False
+        torch.backends.cudnn.allow_tf32 = False
+        self._bufs = None
+        self.update(net)
+
+    def update(self, net: XiangqiNet):
+        ref = InferenceNet(net)
+        dv = lambda t: t.to(self.device).contiguous()
+        self.w_in = ref.w_in.to(self.device).contiguous(memory_format=torch.channels_last)
+        self.b_in = dv(ref.b_in)
+        self.blocks = []
+        for i in range(self.num_res_blocks):
+            self.blocks.append((hip.wino_transform_weights(getattr(ref, f"w1_{i}")).to(self.device), dv(getattr(ref, f"b1_{i}")),
+                                hip.wino_transform_weights(getattr(ref, f"w2_{i}")).to(self.device), dv(getattr(ref, f"b2_{i}"))))
+        self.w_p = dv(ref.w_p.view(ref.w_p.shape[0], -1)); self.b_p = dv(ref.b_p)
+        self.w_v = dv(ref.w_v.view(ref.w_v.shape[0], -1)); self.b_v = dv(ref.b_v)
+        # heads consume NHWC rows: permute the FC weights once from the reference's (c, h, w) flatten order to (hw, c)
+        fp = ref.fc_p_w.view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
+        fv = ref.fc_v1_w.view(-1, 4, 90).permute(0, 2, 1).reshape(-1, 360)
+        self.fc_p_w, self.fc_p_b = dv(fp), dv(ref.fc_p_b)
+        self.fc_v1_w, self.fc_v1_b = dv(fv), dv(ref.fc_v1_b)
+        self.fc_v2_w, self.fc_v2_b = dv(ref.fc_v2_w), dv(ref.fc_v2_b)
+
+    def _buffers(self, b):
+        if self._bufs is None or self._bufs[0].shape[0] != b:
+            self._bufs = [torch.empty((b, 90, self.C), dtype=torch.float32, device=self.device) for _ in range(3)]
+        return self._bufs
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        F = torch.nn.functional
+        b = x.shape[0]
+        h0 = F.conv2d(x.contiguous(memory_format=torch.channels_last), self.w_in, None, padding=1)   # NHWC memory
+        hip.bias_act_(h0, self.b_in)
+        h = h0.permute(0, 2, 3, 1).reshape(b, 90, self.C)           # view: channels-last memory is [B,10,9,C]
+        t1, t2, t3 = self._buffers(b)
+        free = [t1, t2, t3]
+        for u1, b1, u2, b2 in self.blocks:
+            y = next(t for t in free if t.data_ptr() != h.data_ptr())
+            hip.wino_conv3x3(h, u1, b1, y, None, True)
+            o = next(t for t in free if t.data_ptr() != h.data_ptr() and t.data_ptr() != y.data_ptr())
+            hip.wino_conv3x3(y, u2, b2, o, h, True)
+            h = o
+        rows = h.view(b * 90, self.C)
+        p = hip.bias_act_(rows @ self.w_p.t(), self.b_p)             # 1x1 conv == GEMM over NHWC rows
+        logits = F.linear(p.view(b, 2880), self.fc_p_w, self.fc_p_b)
+        v = hip.bias_act_(rows @ self.w_v.t(), self.b_v)
+        v = F.relu(F.linear(v.view(b, 360), self.fc_v1_w, self.fc_v1_b))
+        value = torch.tanh(F.linear(v, self.fc_v2_w, self.fc_v2_b))
+        return logits, value.view(-1)
+
+    def predict(self, state: np.ndarray, device=None):
+        x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
+        logits, value = self(x)
+        return torch.softmax(logits, dim=1).squeeze(0).cpu().numpy(), float(value.item())
