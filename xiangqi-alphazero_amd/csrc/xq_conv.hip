@@ -13,13 +13,16 @@
 //             ci = 8*chunk + 4*quad + j                                        pre-transformed weights (host)
 // Work decomposition: workgroup = 64 tiles (2.56 boards) x 64 output channels, 8 waves.  Wave w owns Winograd
 // row p = w&3 (frequencies xi = 4p..4p+3) for the channel half w>>2: 4 xi x 2 M-tiles x 1 N-tile = 8 accumulator
-// tiles of 32x32 = 128 VGPRs.  Per 8-channel chunk: U arrives by LDS-DMA (global_load_lds, 16 B/lane, linear
-// image), the raw input of the 4 boards a tile group can touch is staged once per 16 channels (80-byte position
-// stride: 2-way instead of 8-way bank conflicts on the strided tile reads), every thread turns one (tile, channel
-// quad, Winograd row) into four B^T d B values for the next chunk while the MFMAs of the current chunk run.
+// tiles of 32x32 = 128 VGPRs.  Per 8-channel chunk: every U element is used by exactly one wave, so the B operand
+// goes global (L2) -> registers, one 16 B load per lane and frequency, issued one chunk ahead -- no LDS and no
+// barrier for it; the raw input of the 4 boards a tile group can touch is staged in LDS once per 16 channels
+// (double-buffered; 80-byte position stride: 2-way instead of 8-way bank conflicts on the strided tile reads);
+// every thread turns one (tile, channel quad, Winograd row) into four B^T d B values for the next chunk.
 // Epilogue: the column half of A^T M A in registers, the row half across the 4 waves of a channel half through
 // LDS (the 128 KB of chunk buffers are reused), then bias + residual + ReLU and coalesced NHWC stores.
 // Blocks are dealt so that each XCD works on one 64-channel slice of U at a time (1 MB at C=256: L2-resident).
+#include <type_traits>
+
 #include "xq_common.h"
 
 #pragma clang fp contract(off)
@@ -36,18 +39,20 @@ constexpr int VBUF_BYTES = 16 * 2 * TILES * 16;   // 32 KB
 constexpr int UBUF_BYTES = 16 * 2 * NCO * 16;     // 32 KB
 constexpr int XPOS = 360;            // 4 boards
 constexpr int XSTRIDE = 80;          // bytes per staged position (16 channels + 16 B pad)
-constexpr int XRAW_BYTES = XPOS * XSTRIDE;
-constexpr int LDS_BYTES = 2 * VBUF_BYTES + 2 * UBUF_BYTES + XRAW_BYTES;
+constexpr int XZERO = XPOS * XSTRIDE;        // a zeroed 16-byte slot behind the staged positions (out-of-board reads)
+constexpr int XRAW_BYTES = (XPOS + 1) * XSTRIDE;
+constexpr int E_BYTES = 16 * TILES * 32 * 4;       // epilogue exchange planes (128 KB) reuse the whole image
+constexpr int LDS_BYTES = (2 * VBUF_BYTES + 2 * XRAW_BYTES) > E_BYTES ? (2 * VBUF_BYTES + 2 * XRAW_BYTES) : E_BYTES;
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 
 __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ X, const float *__restrict__ Ug,
                                                       const float *__restrict__ bias, const float *__restrict__ R,
-                                                      float *__restrict__ Y, int B, int C, int relu, int n_groups) {
+                                                      float *__restrict__ Y, int B, int C, int relu, int n_groups,
+                                                      unsigned long long *__restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Vb = lds;                                   // [2][16][2][64] float4
-    char *Ub = lds + 2 * VBUF_BYTES;                  // [2][16][2][64] float4
-    char *Xr = lds + 2 * VBUF_BYTES + 2 * UBUF_BYTES; // [360][80 B]
+    char *Xr = lds + 2 * VBUF_BYTES;                  // [2][360][80 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NG = C / NCO;                           // channel groups; divides 8
@@ -56,6 +61,8 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
     const int cog = xcd % NG;
     const int tg = rr * per + xcd / NG;
     if (tg >= n_groups) return;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (stamps) st0 = __builtin_amdgcn_s_memrealtime();
     const int T = B * 25;
     const int t0 = tg * TILES;
     const int b_lo = t0 / 25;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
     const int tb = gt / 25, tt = gt - tb * 25, ty = tt / 5, tx = tt - ty * 5;
     const int r1 = tr_i == 0 ? 0 : 1, r2 = tr_i == 3 ? 3 : 2;
     const float s1 = tr_i == 2 ? -1.0f : 1.0f, s2 = (tr_i == 0 || tr_i == 3) ? -1.0f : 1.0f;
-    int xoff[2][4];                                   // byte offsets into Xr, or -1 when out of the board
+    int xoff[2][4];                                   // byte offsets into Xr (the zero slot when out of the board)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int y = 2 * ty - 1 + (k == 0 ? r1 : r2);
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
         for (int c = 0; c < 4; ++c) {
             const int x = 2 * tx - 1 + c;
             const bool ok = tile_ok && (unsigned)y < 10u && (unsigned)x < 9u;
-            xoff[k][c] = ok ? ((tb - b_lo) * 90 + y * 9 + x) * XSTRIDE : -1;
+            xoff[k][c] = ok ? ((tb - b_lo) * 90 + y * 9 + x) * XSTRIDE : XZERO;
         }
     }
     // staging role: 1440 float4 per 16-channel superchunk, 3 per thread
@@ -106,15 +113,12 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[q][m][e] = 0.0f;
 
-    auto dma_u = [&](int chunk, int buf) {
-        const float *src = ug + (size_t)chunk * (UBUF_BYTES / 4);
+    // B operand: lane (h, n) of wave (p, half) needs U[xi][8*chunk + 4h + j][64*cog + 32*half + n], j = 0..3
+    const unsigned ul = (h * (NCO * 4) + (wch * 32 + l31) * 4 + (wp * 4) * (2 * NCO * 4)) * 4;   // byte offset in a chunk
+    auto load_u = [&](int chunk, f32x4 *dst) {
+        const char *src = (const char *)(ug + (size_t)chunk * (UBUF_BYTES / 4));                  // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int kb = wave + 8 * k;              // KB index inside the 32 KB chunk
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + kb * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void *)(Ub + buf * UBUF_BYTES + kb * 1024),
-                                             16, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) dst[q] = *(const f32x4 *)(src + ul + q * (2 * NCO * 16));
     };
     f32x4 xreg[3];
     auto load_x = [&](int super) {
@@ -124,20 +128,18 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
             xreg[k] = xv[k] ? *(const f32x4 *)(xg[k] + super * 16) : z;
         }
     };
-    auto store_x = [&]() {
+    auto store_x = [&](int super) {
+        char *dst = Xr + (super & 1) * XRAW_BYTES;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (tid + 512 * k < XPOS * 4) *(f32x4 *)(Xr + xl[k]) = xreg[k];
+            if (tid + 512 * k < XPOS * 4) *(f32x4 *)(dst + xl[k]) = xreg[k];
     };
     auto transform = [&](int chunk, int buf) {
-        const int sub = ((chunk & 1) * 2 + tr_qd) * 16;
+        const char *xr = Xr + ((chunk >> 1) & 1) * XRAW_BYTES + ((chunk & 1) * 2 + tr_qd) * 16;
         f32x4 w[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            const f32x4 d1 = xoff[0][c] >= 0 ? ld4(Xr + xoff[0][c] + sub) : z;
-            const f32x4 d2 = xoff[1][c] >= 0 ? ld4(Xr + xoff[1][c] + sub) : z;
-            w[c] = s1 * d1 + s2 * d2;
+            w[c] = s1 * ld4(xr + xoff[0][c]) + s2 * ld4(xr + xoff[1][c]);
         }
         char *dst = Vb + buf * VBUF_BYTES + ((tr_i * 4) * 2 + tr_qd) * (TILES * 16) + tr_tile * 16;
         *(f32x4 *)(dst + 0 * 2 * TILES * 16) = w[0] - w[2];
@@ -145,46 +147,94 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
         *(f32x4 *)(dst + 2 * 2 * TILES * 16) = w[2] - w[1];
         *(f32x4 *)(dst + 3 * 2 * TILES * 16) = w[1] - w[3];
     };
+    // One chunk of work for a wave: 32 MFMAs on V[buf] x u, with the B^T d B transform of chunk `nchunk` into
+    // V[buf^1] threaded between them.  A 64-cycle fp32 MFMA leaves ~56 issue cycles before the pipe takes the next
+    // one; ~4 vector/LDS instructions per MFMA ride in that shadow.  Clustered (8 MFMAs, then 25 VALU) they do
+    // not: the cluster delays the next MFMA.  sched_group_barrier pins the interleave.
+    // One chunk of work for a wave: 32 MFMAs on V[buf] x u, with the B^T d B transform of chunk `nchunk` into
+    // V[buf^1] threaded between them.  On gfx950 the fp32 MFMA runs at exactly the fp32 VALU rate and, measured here,
+    // every other vector instruction a SIMD issues adds its issue time to the MFMA stream (no co-execution as with
+    // the bf16 matrix core): the lever is the COUNT of non-MFMA vector instructions.  The transform is therefore
+    // specialised per Winograd row (ROW is wave-uniform: waves 2r, 2r+1 own row r) so that the +-1 coefficients of
+    // B^T become add/sub operand order instead of multiplies.
+    auto chunk_body = [&](int buf, const f32x4 *u, int nchunk, auto row_tag) {
+        constexpr int ROW = decltype(row_tag)::value;
+        const char *vb = Vb + buf * VBUF_BYTES + h * (TILES * 16) + l31 * 16 + (wp * 4) * (2 * TILES * 16);
+        const char *xr = Xr + ((nchunk >> 1) & 1) * XRAW_BYTES + ((nchunk & 1) * 2 + tr_qd) * 16;
+        char *dst = Vb + (buf ^ 1) * VBUF_BYTES + ((ROW * 4) * 2 + tr_qd) * (TILES * 16) + tr_tile * 16;
+        f32x4 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a0 = ld4(vb + q * (2 * TILES * 16));
+            const f32x4 a1 = ld4(vb + q * (2 * TILES * 16) + 32 * 16);
+            const f32x4 d1 = ld4(xr + xoff[0][q]), d2 = ld4(xr + xoff[1][q]);
+            w[q] = ROW == 0 ? d1 - d2 : ROW == 1 ? d1 + d2 : ROW == 2 ? d2 - d1 : d1 - d2;   // rows of B^T d
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], u[q][j], acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], u[q][j], acc[q][1], 0, 0, 0);
+            }
+        }
+        *(f32x4 *)(dst + 0 * 2 * TILES * 16) = w[0] - w[2];
+        *(f32x4 *)(dst + 1 * 2 * TILES * 16) = w[1] + w[2];
+        *(f32x4 *)(dst + 2 * 2 * TILES * 16) = w[2] - w[1];
+        *(f32x4 *)(dst + 3 * 2 * TILES * 16) = w[1] - w[3];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {                // pin the interleave: per MFMA one LDS read and a little VALU
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            if (i >= 28) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
 
     // ---- prologue ------------------------------------------------------------------------------------------
+    const int NSUP = NCH / 2;
+    f32x4 uA[4], uB[4];
     load_x(0);
-    dma_u(0, 0);
-    store_x();
+    load_u(0, uA);
+    if (tid < 8) {                                    // zero slots of both staging buffers (4 x 16 B cover the sub offsets)
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        *(f32x4 *)(Xr + (tid >> 2) * XRAW_BYTES + XZERO + (tid & 3) * 16) = z;
+    }
+    store_x(0);
     __syncthreads();
-    if (NCH > 2) load_x(1);
+    if (NSUP > 1) load_x(1);
     transform(0, 0);
     __syncthreads();
 
-    // ---- main loop over 8-channel chunks -------------------------------------------------------------------
-    for (int c = 0; c < NCH; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < NCH;
-        const bool new_super = more && (c & 1);       // chunk c+1 starts a 16-channel superchunk
-        if (more) dma_u(c + 1, buf ^ 1);
-        if (new_super) store_x();                     // last readers of Xr finished before the previous barrier
-
-        const char *vb = Vb + buf * VBUF_BYTES + h * (TILES * 16) + l31 * 16;
-        const char *ub = Ub + buf * UBUF_BYTES + h * (NCO * 16) + (wch * 32 + l31) * 16;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int xi = wp * 4 + q;
-            const f32x4 a0 = ld4(vb + xi * (2 * TILES * 16));
-            const f32x4 a1 = ld4(vb + xi * (2 * TILES * 16) + 32 * 16);
-            const f32x4 bb = ld4(ub + xi * (2 * NCO * 16));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[j], acc[q][0], 0, 0, 0);
-                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[j], acc[q][1], 0, 0, 0);
-            }
+    if (stamps) st1 = __builtin_amdgcn_s_memrealtime();
+    // ---- main loop, two 8-channel chunks per trip (U register sets alternate) ------------------------------
+    // An MFMA-issuing wave blocks its own later instructions (in-order issue), and two SIMD partners that run the
+    // same program in step queue on the matrix pipe together and then leave it idle together.  Waves w and w+4
+    // share a SIMD: waves 0-3 run [MFMA(c), transform(c+1)], waves 4-7 run [transform(c+1), MFMA(c)] -- both
+    // orders are legal inside a chunk -- so one partner's matrix work covers the other's vector/LDS work.
+    auto run_chunk = [&](int buf, const f32x4 *u, int nchunk) {
+        switch (tr_i) {                               // wave-uniform
+        case 0: chunk_body(buf, u, nchunk, std::integral_constant<int, 0>{}); break;
+        case 1: chunk_body(buf, u, nchunk, std::integral_constant<int, 1>{}); break;
+        case 2: chunk_body(buf, u, nchunk, std::integral_constant<int, 2>{}); break;
+        default: chunk_body(buf, u, nchunk, std::integral_constant<int, 3>{}); break;
         }
-        if (new_super) {
-            __syncthreads();                          // staged input of the new superchunk visible
-            if (c + 3 < NCH) load_x((c + 3) >> 1);
+    };
+    for (int c = 0; c < NCH; c += 2) {
+        const int sup = c >> 1;
+        // even chunk c: V[0], U set A; next chunk's U and the staging of superchunk sup+1 are fetched first
+        load_u(c + 1, uB);
+        if (sup + 1 < NSUP) {
+            store_x(sup + 1);                         // this buffer was last read two chunks ago
+            if (sup + 2 < NSUP) load_x(sup + 2);
         }
-        if (more) transform(c + 1, buf ^ 1);
+        run_chunk(0, uA, c + 1);
+        __syncthreads();
+        // odd chunk c+1: V[1], U set B.  On the last trip the prefetch/transform targets are clamped (harmless
+        // redundant work into buffers nobody reads) so the body stays one straight-line scheduling region.
+        const int nc = c + 2 < NCH ? c + 2 : c;
+        load_u(nc, uA);
+        run_chunk(1, uB, nc);
         __syncthreads();
     }
-
+    if (stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue: Y = A^T M A, bias, residual, ReLU --------------------------------------------------------
     // column half in registers: b=0: M0+M1+M2, b=1: M1-M2-M3 (A^T = [[1,1,1,0],[0,1,-1,-1]])
     float *E = (float *)lds;                          // [16 planes][64 tiles][32 co], plane = (wch*4 + wp)*2 + b
@@ -222,6 +272,14 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
         if (relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
         *(f32x4 *)(Y + o) = y;
     }
+    if (stamps && lane == 0) {                        // diagnostic path only (xq_wino_conv3x3_dbg)
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *d = stamps + (size_t)blockIdx.x * 16;
+        if (wave == 0) { d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memrealtime(); d[4] = xcc; }
+        d[8 + wave] = hwid;
+    }
 }
 
 }  // namespace
@@ -247,7 +305,22 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     const int per = 8 / ng;
     const int rows = (n_groups + per - 1) / per;
     hipLaunchKernelGGL(k_wino_conv, dim3(rows * 8), dim3(512), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
-                       dev_residual, dev_y, batch, channels, relu, n_groups);
+                       dev_residual, dev_y, batch, channels, relu, n_groups, (unsigned long long *)nullptr);
+    return xq::launch_status();
+}
+
+/* diagnostic twin: per-block 100 MHz timestamps {start, after prologue, after main loop, end, HW_ID, XCC_ID} into
+ * dev_stamps[grid][16] (grid = 8 * ceil(ceil(batch*25/64) / (8 / (channels/64)))).  Not part of the product path. */
+int xq_wino_conv3x3_dbg(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual, float *dev_y,
+                        int batch, int channels, int relu, unsigned long long *dev_stamps, void *stream) {
+    if (!dev_x || !dev_u || !dev_bias || !dev_y || batch <= 0 || !dev_stamps) return XQ_ERR_ARG;
+    if (channels < 64 || channels % 64 || 8 % (channels / 64)) return XQ_ERR_ARG;
+    XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    const int n_groups = (batch * 25 + TILES - 1) / TILES;
+    const int per = 8 / (channels / NCO);
+    const int rows = (n_groups + per - 1) / per;
+    hipLaunchKernelGGL(k_wino_conv, dim3(rows * 8), dim3(512), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+                       dev_residual, dev_y, batch, channels, relu, n_groups, dev_stamps);
     return xq::launch_status();
 }
 

@@ -12,7 +12,7 @@ import subprocess
 import torch  # imported BEFORE the library is loaded: both must share one HIP runtime (libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxq_hip.so")
+LIB_PATH = os.environ.get("XQ_HIP_LIB", os.path.join(_HERE, "libxq_hip.so"))   # override: perf experiments only
 CSRC = os.path.join(_HERE, "csrc")
 
 MAXM = 128
