@@ -80,6 +80,8 @@ def main():
         eng.step()
     sync()
     s0 = eng.stats()
+    if hasattr(ev, "timing"):
+        ev.timing = True            # HIP events around each launch of the dominant kernel, timed region only
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):

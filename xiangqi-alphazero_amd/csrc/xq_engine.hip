@@ -262,6 +262,7 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
     int ovf = 0;
     // per-lane stat deltas are kept wave-uniform and written by lane 0 at the end
     unsigned long long d_sims = 0, d_term = 0, d_moves = 0, d_depth = 0, d_scan = 0;
+    int term_run = 0;
 
     lds_copy_dwords(L.root, g_board, XQ_BS / 4);
     lds_copy_dwords(L.rhist, g_hist, XQ_HIST * XQ_BS / 4);
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
             uint8_t *rec = E.stage + ((size_t)slot * E.stage_cap + (n_samples < E.stage_cap ? n_samples : E.stage_cap - 1)) * XQ_SAMPLE_BYTES;
             if (n_samples >= E.stage_cap) ovf |= 4;
             for (int i = lane; i < XQ_SAMPLE_BYTES / 4; i += 64) ((uint32_t *)rec)[i] = 0u;
-            wave_sync();
+            wave_sync_mem();
             for (int i = lane; i < 90; i += 64) rec[i] = (uint8_t)L.root[i];
             if (lane == 0) {
                 xq_sample *s = (xq_sample *)rec;
@@ -487,10 +488,14 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
         int cnt, winner;
         const bool term = wave_game_over(L.board, L.hist, side, mc, nocap, L.mg, L.moves, &cnt, &winner, &ovf);
         if (term) {
-            wave_sync();   // path[] stores of lane 0 must be visible to the other lanes
+            wave_sync_mem();   // path[] stores of lane 0 must be visible to the other lanes
             wave_backup(tN, tW, path, depth, winner == 0 ? 0.0 : 1.0);   // mcts.py:137-140
-            wave_sync();
+            wave_sync_mem();   // the next descent reads N/W written here by other lanes
             sims_done += 1; d_sims += 1; d_term += 1;
+            // A root with a mating reply re-tests that terminal child on every visit (as mcts.py does); bound how
+            // many such simulations one launch runs so a single slot cannot stretch the step (it resumes next step
+            // and hands the evaluator no position this time).
+            if (++term_run >= 48) break;
             continue;
         }
         wave_encode(L.board, side, nn_in + (size_t)slot * XQ_STATE_FLOATS);
@@ -551,9 +556,9 @@ __global__ __launch_bounds__(64) void k_expand(Dev E, const float *__restrict__ 
             const int K = E.cfg.resign_check_steps;
             double *rh = E.resign + (size_t)slot * 16;
             int rn = gi[GI_RESIGN_N];
-            wave_sync();
+            wave_sync_mem();
             if (lane == 0) { rh[rn % 16] = v_net; gi[GI_RESIGN_N] = rn + 1; }
-            wave_sync();
+            wave_sync_mem();
             rn += 1;
             if (rn >= K) {
                 bool all_low = true;
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(64) void k_expand(Dev E, const float *__restrict__ 
     }
     // ---- leaf: value = -v (mcts.py:150), backup
     const int depth = __builtin_amdgcn_readfirstlane(gi[GI_PDEPTH]);
-    wave_sync();
+    wave_sync_mem();
     wave_backup(tN, tW, path, depth, -v_net);
     sims_done += 1;
     if (lane == 0) {

@@ -25,8 +25,13 @@ namespace xq {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
-// All engine kernels run ONE wavefront per workgroup, so the workgroup barrier is a wave-level LDS fence.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// All engine kernels run ONE wavefront per workgroup.  LDS operations of one wave execute in issue order, so
+// lane-to-lane communication through LDS needs no barrier -- only that the compiler keeps the order (the "memory"
+// clobber) and that pending LDS returns have landed.  A full __syncthreads() here would also wait for every
+// outstanding GLOBAL store (vmcnt(0)) -- a ~1-2 us stall per call in the tree walk.
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Same, plus global memory: lane A's global stores become visible to lane B's later loads of the same wave.
+__device__ __forceinline__ void wave_sync_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));

@@ -25,6 +25,8 @@ class HipResNetEvaluator:
         torch.backends.cuda.matmul.allow_tf32 = False
         torch.backends.cudnn.allow_tf32 = False
         self._bufs = None
+        self.timing = False          # bench.py: HIP events around every conv launch of the timed region
+        self._events = []
         self.update(net)
 
     def update(self, net: XiangqiNet):
@@ -61,9 +63,9 @@ class HipResNetEvaluator:
         free = [t1, t2, t3]
         for u1, b1, u2, b2 in self.blocks:
             y = next(t for t in free if t.data_ptr() != h.data_ptr())
-            hip.wino_conv3x3(h, u1, b1, y, None, True)
+            self._conv(h, u1, b1, y, None)
             o = next(t for t in free if t.data_ptr() != h.data_ptr() and t.data_ptr() != y.data_ptr())
-            hip.wino_conv3x3(y, u2, b2, o, h, True)
+            self._conv(y, u2, b2, o, h)
             h = o
         rows = h.view(b * 90, self.C)
         p = hip.bias_act_(rows @ self.w_p.t(), self.b_p)             # 1x1 conv == GEMM over NHWC rows
@@ -72,6 +74,36 @@ class HipResNetEvaluator:
         v = F.relu(F.linear(v.view(b, 360), self.fc_v1_w, self.fc_v1_b))
         value = torch.tanh(F.linear(v, self.fc_v2_w, self.fc_v2_b))
         return logits, value.view(-1)
+
+    def _conv(self, x, u, b, out, residual):
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.wino_conv3x3(x, u, b, out, residual, True)
+            e1.record()
+            self._events.append((e0, e1))
+        else:
+            hip.wino_conv3x3(x, u, b, out, residual, True)
+
+    def roofline(self, batch: int, nn_ms: float):
+        """bench.py roofline object for the dominant kernel (k_wino_conv): algorithmic FLOPs of the 3x3 convolution
+        it computes (2*90*9*C*C per position, SURVEY.md section 8a row a17 share) x positions per launch, over the
+        average launch duration measured with HIP events on the launch stream."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize(self.device)
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        avg = sum(ms) / len(ms)
+        direct = 2.0 * 90 * 9 * self.C * self.C * batch
+        tiles = (batch * 25 + 63) // 64 * 64
+        mfma = 16 * 2.0 * tiles * self.C * self.C
+        ach = direct / (avg * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "k_wino_conv (fused Winograd F(2x2,3x3) 3x3 conv, fp32 MFMA 32x32x2)",
+                "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+                "launches_timed": len(ms), "avg_launch_ms": round(avg, 4),
+                "algorithmic_flops_per_launch": direct, "mfma_flops_per_launch": mfma,
+                "mfma_issue_rate_tflops": round(mfma / (avg * 1e-3) / 1e12, 2),
+                "share_of_evaluate_ms": round(avg * 2 * self.num_res_blocks / nn_ms, 4)}
 
     def predict(self, state: np.ndarray, device=None):
         x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
