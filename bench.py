@@ -112,6 +112,17 @@ def main():
     if rank == 0:
         flops_eval, flops_tower = net_flops(args.channels, args.blocks)
         roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
+        if roof is not None and args.games == 8192 and args.channels == 256:
+            # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE, separate runs of this same command): counters cannot be read from inside this process.
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                fk = [v for k, v in pmc["FETCH_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
+                wk = [v for k, v in pmc["WRITE_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
+                roof["traffic"] = int((2 * fk + wk) * 1024)     # gfx950: FETCH_SIZE counts 16-B/lane reads at half
+                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+            except Exception:
+                pass
         if roof is None:
             achieved = flops_eval * args.games / (nn_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "ResNet forward (%s), whole-network FLOPs / event-timed forward" % ev_name,
