@@ -236,6 +236,25 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
     }
     if (stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue: Y = A^T M A, bias, residual, ReLU --------------------------------------------------------
+    // Output coordinates and the residual loads come first: their HBM latency then hides behind the register
+    // reduction and the LDS exchange (the prefetch registers of the main loop are dead by now).
+    const int c4 = tid & 15;
+    const int co = c4 * 4, ech = co >> 5, ecol = co & 31;
+    const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + co);
+    size_t oaddr[8];
+    f32x4 resv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int pidx = it * 32 + (tid >> 4);
+        const int tile = pidx >> 2, a = (pidx >> 1) & 1, b = pidx & 1;
+        const int g = t0 + tile;
+        const int bd = g / 25, t2 = g - bd * 25, ty2 = t2 / 5, tx2 = t2 - ty2 * 5;
+        const int oy = 2 * ty2 + a, ox = 2 * tx2 + b;
+        const bool ok = g < T && ox < 9;
+        oaddr[it] = ok ? ((size_t)bd * 90 + oy * 9 + ox) * C + cog * NCO + co : (size_t)-1;
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        resv[it] = (ok && R) ? *(const f32x4 *)(R + oaddr[it]) : z;
+    }
     // column half in registers: b=0: M0+M1+M2, b=1: M1-M2-M3 (A^T = [[1,1,1,0],[0,1,-1,-1]])
     float *E = (float *)lds;                          // [16 planes][64 tiles][32 co], plane = (wch*4 + wp)*2 + b
 #pragma unroll
@@ -250,27 +269,19 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
         }
     }
     __syncthreads();
-    const int c4 = tid & 15;
-    const int co = c4 * 4, ech = co >> 5, ecol = co & 31;
-    const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + co);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int pidx = it * 32 + (tid >> 4);
         const int tile = pidx >> 2, a = (pidx >> 1) & 1, b = pidx & 1;
-        const int g = t0 + tile;
-        const int bd = g / 25, t2 = g - bd * 25, ty2 = t2 / 5, tx2 = t2 - ty2 * 5;
-        const int oy = 2 * ty2 + a, ox = 2 * tx2 + b;
-        if (g >= T || ox >= 9) continue;
+        if (oaddr[it] == (size_t)-1) continue;
         const float *e0 = E + (((ech * 4) * 2 + b) * TILES + tile) * 32 + ecol;
         const int pstride = 2 * TILES * 32;           // next Winograd row p
         f32x4 y;
         if (a == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
         else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
-        const size_t o = ((size_t)bd * 90 + oy * 9 + ox) * C + cog * NCO + co;
-        y = y + bv;
-        if (R) y = y + *(const f32x4 *)(R + o);
+        y = y + bv + resv[it];
         if (relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
-        *(f32x4 *)(Y + o) = y;
+        *(f32x4 *)(Y + oaddr[it]) = y;
     }
     if (stamps && lane == 0) {                        // diagnostic path only (xq_wino_conv3x3_dbg)
         unsigned hwid, xcc;
