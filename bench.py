@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--evaluator", default="auto", choices=["auto", "torch", "nhwc", "hip"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--prewarm", type=int, default=-1,
+                    help="untimed steps with a zero-logit evaluator that bring the staggered slots to the steady-state "
+                         "mix of search depths before warm-up (-1: sims+64, 0: off)")
     args = ap.parse_args()
 
     import torch
@@ -65,7 +68,8 @@ def main():
     net.load_state_dict(weights.make_state_dict(args.channels, args.blocks))
     ev, ev_name = evaluator.make_evaluator(net, dev, args.evaluator)
     cfg = engine.make_config(args.games, args.sims, max_game_length=400, random_opening_moves=8,
-                             temperature_threshold=20, enable_resign=True, seed=args.seed, rank=rank)  # "full" preset
+                             temperature_threshold=20, enable_resign=True, seed=args.seed, rank=rank,   # "full" preset
+                             start_stagger=True)
     eng = engine.SelfPlayEngine(cfg, dev, evaluator=ev)
 
     ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(4 * args.steps)]
@@ -76,6 +80,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # steady state: slots start staggered over one move's worth of steps; a zero-logit evaluator
+    # (uniform priors, value 0 -- no network) advances them until every slot is somewhere inside a search.
+    prewarm = args.sims + 64 if args.prewarm < 0 else args.prewarm
+    if prewarm:
+        z_logits = torch.zeros((args.games, 8100), dtype=torch.float32, device=dev)
+        z_value = torch.zeros(args.games, dtype=torch.float32, device=dev)
+        for _ in range(prewarm):
+            eng.select()
+            eng.expand(z_logits, z_value, False)
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         eng.step()
     sync()
@@ -139,7 +153,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: %d concurrent games per GPU, %d sims/move, %dch x %dblk ResNet"
                        % (args.games, args.sims, args.channels, args.blocks),
                        "games_per_gpu": args.games, "sims_per_move": args.sims, "net": "%dx%d" % (args.channels, args.blocks),
-                       "evaluator": ev_name, "parallelism": "games sharded across ranks, no data-path collective"},
+                       "evaluator": ev_name, "prewarm_steps": prewarm, "parallelism": "games sharded across ranks, no data-path collective"},
             "roofline": roof,
             "breakdown_ms": {"select": round(sel_ms, 3), "evaluate": round(nn_ms, 3), "expand_backup": round(exp_ms, 3)},
             "tree": {"mean_depth": round(d_depth / max(sims, 1), 3), "children_read_per_sim": round(d_scan / max(sims, 1), 2),

@@ -120,7 +120,8 @@ typedef struct xq_engine_config {
     int32_t max_out_results;       /* capacity of the game-result ring */
     int32_t manual_moves;          /* 1: search only -- never plays the move (xq_engine_set_position +
                                       num_simulations steps, then xq_engine_read_root); used for MCTS.search parity */
-    int32_t reserved;
+    int32_t start_stagger;         /* 1: slot s idles hash(s) mod (num_simulations+1) steps before its first game, so a
+                                      freshly initialised engine reaches the steady-state mix of search depths */
 } xq_engine_config;
 
 /* Host-side handle: plain pointers into the caller's workspace.  Treat as opaque. */

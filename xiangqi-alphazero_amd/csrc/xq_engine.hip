@@ -36,7 +36,7 @@ enum Phase : int { PH_NEWGAME = 0, PH_NEWPOS = 1, PH_WAIT_ROOT = 2, PH_SEARCH = 
 
 enum Gi : int { GI_SIDE = 0, GI_MC, GI_NOCAP, GI_PHASE, GI_SIMS, GI_NSAMP, GI_GSEQ, GI_ALLOC, GI_PLEAF, GI_PDEPTH,
                 GI_PCOUNT, GI_RSTATUS, GI_RWINNER, GI_RESIGN_N, GI_RNG0, GI_RNG1, GI_RNG2, GI_RNG3, GI_FWINNER,
-                GI_FREASON, GI_MANNOISE, GI_N = 32 };
+                GI_FREASON, GI_MANNOISE, GI_DELAY, GI_N = 32 };
 
 enum St : int { ST_SIMS = 0, ST_TERM, ST_LEAF, ST_ROOT, ST_MOVES, ST_GAMES, ST_RED, ST_BLACK, ST_DRAW, ST_PLIES, ST_NODES,
                 ST_DEPTH, ST_SCAN, ST_RESIGN, ST_SAMP, ST_DROP, ST_OVF, ST_STARTED, ST_N = 32 };
@@ -250,6 +250,11 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
 
     int phase = __builtin_amdgcn_readfirstlane(gi[GI_PHASE]);
     if (phase == PH_IDLE || phase == PH_HOLD || phase == PH_WAIT_ROOT || phase == PH_WAIT_LEAF) return;
+    const int delay = __builtin_amdgcn_readfirstlane(gi[GI_DELAY]);
+    if (delay > 0) {                                  // start_stagger: not started yet
+        if (lane == 0) gi[GI_DELAY] = delay - 1;
+        return;
+    }
 
     int g_side = __builtin_amdgcn_readfirstlane(gi[GI_SIDE]);
     int g_mc = __builtin_amdgcn_readfirstlane(gi[GI_MC]);
@@ -697,6 +702,8 @@ __global__ void k_init(Dev E) {
     for (int i = 0; i < GI_N; ++i) gi[i] = 0;
     gi[GI_PHASE] = E.cfg.manual_moves ? PH_HOLD : PH_NEWGAME;
     gi[GI_SIDE] = 1;
+    if (E.cfg.start_stagger && !E.cfg.manual_moves)
+        gi[GI_DELAY] = (int)(philox_u64(E.cfg.seed, (uint32_t)E.cfg.rank, (uint32_t)slot, 7u, 0u, 0u) % (uint64_t)(E.cfg.num_simulations + 1));
     unsigned long long *st = E.stats + (size_t)slot * ST_N;
     for (int i = 0; i < ST_N; ++i) st[i] = 0;
     if (slot == 0) { E.cnt[0] = 0; E.cnt[1] = 0; *E.started = 0; }

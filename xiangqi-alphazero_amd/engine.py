@@ -29,7 +29,8 @@ def make_config(n_games: int, num_simulations: int, *, c_puct: float = 1.5, temp
                 resign_threshold: float = -0.9, resign_check_steps: int = 5, add_noise: bool = True,
                 dirichlet_alpha: float = 0.3, noise_eps: float = 0.25, late_temperature: float = 0.3,
                 seed: int = 0, rank: int = 0, inject_len: int = 0, games_target: int = 0,
-                max_out_samples: int = 0, max_out_results: int = 0, manual_moves: bool = False) -> hip.EngineConfig:
+                max_out_samples: int = 0, max_out_results: int = 0, manual_moves: bool = False,
+                start_stagger: bool = False) -> hip.EngineConfig:
     """Defaults are the reference's TrainingConfig (training/train.py:55-111) and hard-coded constants
     (mcts.py:118-121, parallel_selfplay.py:92)."""
     if max_out_samples <= 0:
@@ -39,7 +40,7 @@ def make_config(n_games: int, num_simulations: int, *, c_puct: float = 1.5, temp
     return hip.EngineConfig(n_games, num_simulations, c_puct, temperature_threshold, max_game_length,
                             random_opening_moves, int(enable_resign), resign_threshold, resign_check_steps,
                             int(add_noise), dirichlet_alpha, noise_eps, late_temperature, seed, rank, inject_len,
-                            games_target, max_out_samples, max_out_results, int(manual_moves), 0)
+                            games_target, max_out_samples, max_out_results, int(manual_moves), int(start_stagger))
 
 
 class SelfPlayEngine:

@@ -44,7 +44,7 @@ class EngineConfig(C.Structure):
                 ("dirichlet_alpha", C.c_double), ("noise_eps", C.c_double), ("late_temperature", C.c_double),
                 ("seed", C.c_uint64), ("rank", C.c_int32), ("inject_len", C.c_int32),
                 ("games_target", C.c_int64), ("max_out_samples", C.c_int32), ("max_out_results", C.c_int32),
-                ("manual_moves", C.c_int32), ("reserved", C.c_int32)]
+                ("manual_moves", C.c_int32), ("start_stagger", C.c_int32)]
 
 
 class Engine(C.Structure):
