@@ -175,6 +175,14 @@ def main():
         # from the measured simulation rate with the reference's own game-length bound (<= 200 plies, game.py:595).
         out["games_per_hour_derived"] = {"at_200_plies": round(out["value"] * 3600 / (args.sims * 200.0), 1),
                                          "at_100_plies": round(out["value"] * 3600 / (args.sims * 100.0), 1)}
+        try:    # mean game length MEASURED by tools/measure_games_per_hour.py (1024 complete games, configs[1])
+            gp = json.load(open(os.path.join(ROOT, "profiles", "r01_games_per_hour_cfg1_1024x400_128x6.json")))
+            mp = gp["plies_per_game"]["mean"]
+            out["games_per_hour_derived"]["at_measured_mean_plies"] = round(out["value"] * 3600 / (args.sims * mp), 1)
+            out["games_per_hour_derived"]["measured_mean_plies"] = mp
+            out["games_per_hour_measured_configs1"] = {"games_per_hour": gp["games_per_hour"], "config": gp["config"]}
+        except Exception:
+            pass
         if args.cpu_seconds > 0 and world == 1:
             from oracle import cpu_baseline                      # the checker, timed beside the product path
             cb = cpu_baseline.run(args.channels, args.blocks, budget_s=args.cpu_seconds)
