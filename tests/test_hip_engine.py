@@ -222,3 +222,42 @@ def test_selfplay_device_rng_invariants(eng_mod):
     assert len({bytes(s["board"]) for s in first[first["ply"] == first["ply"].min()]}) >= 1
     assert len({int(s["ply"]) for s in first}) > 3
     del torch
+
+
+def test_search_with_real_network_matches_cpu_reference_path(eng_mod):
+    """End to end within tolerance: GPU engine + hand-written tower evaluator vs the oracle search driven by the
+    torch CPU module's `.predict` (the reference's own evaluator protocol), same generator weights, 64x3 net,
+    96 simulations, no noise.  Network outputs agree to ~1e-6, so visit counts may differ only where two PUCT scores
+    are within that noise: require exact equality on most positions and a small total deviation."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    torch.set_num_threads(8)
+    net = model.XiangqiNet(64, 3)
+    net.load_state_dict(weights.make_state_dict(64, 3, policy_gain=6.0))     # peaked enough for trees to go deep
+    net.eval()
+    ev, name = evaluator.make_evaluator(net, "cuda", "hip")
+    d = G.corpus()
+    picks = [i for i in range(11, len(d["board"]), 400) if not d["done"][i]][:10]
+    sims = 96
+    eng = eng_mod.SelfPlayEngine(eng_mod.make_config(len(picks), sims, add_noise=False, manual_moves=True), evaluator=ev)
+    games = []
+    for slot, i in enumerate(picks):
+        first = i - d["ply"][i]
+        g = _replay([int(a) for a in d["taken"][first:i]])
+        games.append(g)
+        _set_from_game(eng, slot, g)
+    for _ in range(sims + 1):
+        eng.step()
+    exact, dev, deep = 0, 0, 0
+    for slot, g in enumerate(games):
+        want = O.mcts_search(g, sims, lambda s: net.predict(s, "cpu"))
+        r = eng.read_root(slot)
+        n = want.n_children
+        assert list(r["actions"]) == list(want.actions[:n]) and r["sims_done"] == sims
+        diff = int(np.abs(np.array(r["visits"]) - np.array(want.visits[:n])).sum())
+        exact += diff == 0
+        dev += diff
+        deep += want.max_depth >= 3
+        np.testing.assert_allclose(r["prior"], np.array(want.prior[:n]), rtol=2e-4, atol=1e-7)
+    assert exact >= len(picks) - 2 and dev <= 8, (exact, dev)
+    assert deep >= 3
