@@ -118,8 +118,11 @@ typedef struct xq_engine_config {
     int64_t games_target;          /* stop starting games after this many (<=0: unlimited) */
     int32_t max_out_samples;       /* capacity of the finished-sample ring */
     int32_t max_out_results;       /* capacity of the game-result ring */
-    int32_t manual_moves;          /* 1: search only -- never plays the move (xq_engine_set_position +
-                                      num_simulations steps, then xq_engine_read_root); used for MCTS.search parity */
+    int32_t manual_moves;          /* 0: self-play.  1: search only -- never plays the move (xq_engine_set_position +
+                                      num_simulations steps, then xq_engine_read_root); MCTS.search parity / serving.
+                                      2: arena games (training/train.py:453-535): no opening, no noise unless add_noise,
+                                      move = first maximum of the visit counts (temperature 0), no samples, no resign,
+                                      a game still running after max_game_length plies is a draw */
     int32_t start_stagger;         /* 1: slot s idles hash(s) mod (num_simulations+1) steps before its first game, so a
                                       freshly initialised engine reaches the steady-state mix of search depths */
 } xq_engine_config;

@@ -699,3 +699,35 @@ int xqo_play_one_game(const xqo_config *cfg, xqo_eval_fn eval, void *ectx, const
     free(probs);
     return stored;
 }
+
+/* ------------------------------------------------------------------------ */
+/* arena game (training/train.py:453-535, one iteration of the eval loop)     */
+
+int xqo_arena_game(xqo_eval_fn eval_new, void *ctx_new, xqo_eval_fn eval_old, void *ctx_old, int new_is_red,
+                   int num_simulations, double c_puct, int max_game_length, int *winner_out, int *steps_out) {
+    xqo_game g;
+    xqo_search_result res;
+    int step = 0, w = 2, done = 0;
+    xqo_game_init(&g);
+    while (step < max_game_length) {
+        const int red_turn = g.player == 1;
+        const int use_new = (new_is_red && red_turn) || (!new_is_red && !red_turn);     /* train.py:479-483 */
+        if (xqo_mcts_search(&g, num_simulations, c_puct, NULL, use_new ? eval_new : eval_old,
+                            use_new ? ctx_new : ctx_old, &res) != 0 || res.n_children == 0) {
+            xqo_game_free(&g);
+            return -1;
+        }
+        int best = 0;                                      /* get_action(temperature=0): first max, mcts.py:197-200 */
+        for (int i = 1; i < res.n_children; ++i)
+            if (res.visits[i] > res.visits[best]) best = i;
+        xqo_game_make_action(&g, res.actions[best]);
+        step++;
+        done = xqo_game_is_over(&g, &w);
+        if (done) break;
+    }
+    if (!done) done = xqo_game_is_over(&g, &w);            /* train.py:494-496 */
+    *winner_out = done ? w : 0;
+    *steps_out = step;
+    xqo_game_free(&g);
+    return 0;
+}

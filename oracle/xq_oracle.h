@@ -132,6 +132,10 @@ int xqo_play_one_game(const xqo_config *cfg, xqo_eval_fn eval, void *ectx,
                       const xqo_rand_source *rs, xqo_sample *samples, int max_samples,
                       int *winner, int *steps, int64_t *sims_done, int64_t *evals_done);
 
+/* one evaluation game: new vs old model, temperature 0, no noise (train.py:453-535) */
+int xqo_arena_game(xqo_eval_fn eval_new, void *ctx_new, xqo_eval_fn eval_old, void *ctx_old, int new_is_red,
+                   int num_simulations, double c_puct, int max_game_length, int *winner_out, int *steps_out);
+
 /* perft from a board (make/unmake via copies), for pinning a2-a5 */
 int64_t xqo_perft(const int8_t *board, int player, int depth);
 

@@ -108,6 +108,8 @@ def lib():
         L.xqo_play_one_game.argtypes = [C.POINTER(Config), EVAL_FN, C.c_void_p, C.POINTER(_RandSource),
                                         C.POINTER(Sample), C.c_int, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.xqo_arena_game.argtypes = [EVAL_FN, C.c_void_p, EVAL_FN, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.xqo_perft.argtypes = [i8p, C.c_int, C.c_int]
         L.xqo_perft.restype = C.c_int64
         _lib = L
@@ -314,3 +316,15 @@ def play_one_game(cfg: dict, predict, randint, choice_index, dirichlet, uniform,
                         actions=np.array(s.actions[:m], dtype=np.uint16),
                         visits=np.array(s.visits[:m], dtype=np.int32)))
     return out, winner.value, steps.value, sims.value, evals.value
+
+
+def arena_game(predict_new, predict_old, new_is_red: bool, num_simulations: int, max_game_length: int, c_puct: float = 1.5):
+    """One evaluation game of the reference's arena (train.py:453-535) -> (winner, steps)."""
+    cn = predict_new if isinstance(predict_new, EVAL_FN) else make_eval(predict_new)
+    co = predict_old if isinstance(predict_old, EVAL_FN) else make_eval(predict_old)
+    w, st = C.c_int(), C.c_int()
+    rc = lib().xqo_arena_game(cn, None, co, None, int(bool(new_is_red)), int(num_simulations), float(c_puct),
+                              int(max_game_length), C.byref(w), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle arena game failed")
+    return w.value, st.value

@@ -17,6 +17,7 @@ Fixtures written (all small):
   mcts_traces.json      reference MCTS.search under tests/stub_eval.py: root visits, W, priors
   game_traces.json      reference _play_one_game with every random draw injected (tests/draws.py)
   flip_perm.npy         8100-entry action permutation of _augment_data
+  arena_traces.json     reference AlphaZeroTrainer._serial_evaluate with stub models: per-game winner/steps, totals
   nn_golden.npz         reference XiangqiNet outputs for generator weights (xiangqi-alphazero_amd/weights.py)
 """
 import argparse
@@ -473,13 +474,63 @@ def gen_nn():
     np.savez_compressed(os.path.join(HERE, "nn_golden.npz"), **out)
 
 
+def gen_arena():
+    """Reference AlphaZeroTrainer._serial_evaluate (train.py:453-535) run unbound on a stand-in `self` whose two models
+    are stub evaluators: per-game winner / steps are read from its own log lines, the totals from its return value."""
+    import logging
+    import re
+    import types
+    cwd = os.getcwd()
+    os.chdir("/tmp")                                   # train.py opens 'training.log' in the cwd at import
+    try:
+        import train as ref_train                      # reference
+    finally:
+        os.chdir(cwd)
+
+    class StubModel(StubEvaluator):
+        def state_dict(self):
+            return {}
+
+        def load_state_dict(self, sd):
+            return None
+
+    out = []
+    for name, games, sims, max_len, new_peaked in (("a", 6, 24, 60, True), ("b", 4, 40, 24, False), ("c", 4, 16, 200, True)):
+        cfg = types.SimpleNamespace(eval_games=games, eval_simulations=sims, c_puct=1.5, max_game_length=max_len,
+                                    eval_win_rate=0.55)
+        fake = types.SimpleNamespace(config=cfg, device="cpu", current_model=StubModel(peaked=new_peaked),
+                                     best_model=StubModel(peaked=not new_peaked))
+        lines = []
+
+        class H(logging.Handler):
+            def emit(self, record):
+                lines.append(record.getMessage())
+
+        h = H()
+        ref_train.logger.addHandler(h)
+        try:
+            stats = ref_train.AlphaZeroTrainer._serial_evaluate(fake)
+        finally:
+            ref_train.logger.removeHandler(h)
+        per_game = []
+        for ln in lines:
+            m = re.search(r"评估对局 (\d+): .*赢家=(.), 步数=(\d+)", ln)
+            if m:
+                per_game.append(dict(game=int(m.group(1)) - 1, winner={"红": 1, "黑": -1, "和": 0}[m.group(2)], steps=int(m.group(3))))
+        assert len(per_game) == games
+        out.append(dict(name=name, eval_games=games, eval_simulations=sims, max_game_length=max_len, new_peaked=new_peaked,
+                        stats={k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in stats.items()}, games=per_game))
+        print("arena", name, stats, [(g["winner"], g["steps"]) for g in per_game])
+    json.dump(out, open(os.path.join(HERE, "arena_traces.json"), "w"))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--perft5", action="store_true")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     steps = dict(perft=lambda: gen_perft(args.perft5), corpus=gen_corpus, crafted=gen_crafted,
-                 mcts=gen_mcts_traces, games=gen_game_traces, nn=gen_nn)
+                 mcts=gen_mcts_traces, games=gen_game_traces, nn=gen_nn, arena=gen_arena)
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

@@ -46,6 +46,11 @@ def game_traces():
     return json.load(open(os.path.join(GOLDEN, "game_traces.json")))
 
 
+@lru_cache(maxsize=None)
+def arena_traces():
+    return json.load(open(os.path.join(GOLDEN, "arena_traces.json")))
+
+
 def flip_perm() -> np.ndarray:
     return np.load(os.path.join(GOLDEN, "flip_perm.npy"))
 

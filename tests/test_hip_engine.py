@@ -261,3 +261,24 @@ def test_search_with_real_network_matches_cpu_reference_path(eng_mod):
         np.testing.assert_allclose(r["prior"], np.array(want.prior[:n]), rtol=2e-4, atol=1e-7)
     assert exact >= len(picks) - 2 and dev <= 8, (exact, dev)
     assert deep >= 3
+
+
+def test_arena_gate_matches_reference(eng_mod):
+    """`_serial_evaluate` on the engine (arena mode) vs the reference's recorded games, stub models, all games
+    of a set concurrently: per-game winner and number of plies, win/draw totals."""
+    import torch
+    from xiangqi_alphazero_amd import arena
+
+    def stub(peaked):
+        def f(x):
+            p, v = _stub_batch(x.cpu().numpy(), [peaked] * x.shape[0])
+            return torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda()
+        return f
+
+    for t in G.arena_traces():
+        res = arena.play_arena(stub(t["new_peaked"]), stub(not t["new_peaked"]), t["eval_games"], t["eval_simulations"],
+                               t["max_game_length"], policy_is_probs=True)
+        assert [int(r["slot"]) for r in res] == list(range(t["eval_games"]))
+        for r, g in zip(res, t["games"]):
+            assert (int(r["winner"]), int(r["steps"])) == (g["winner"], g["steps"]), (t["name"], g)
+            assert int(r["n_samples"]) == 0

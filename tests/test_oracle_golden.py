@@ -185,3 +185,21 @@ def test_choice_from_uniform_matches_numpy():
         rs.set_state(st)
         want = rs.choice(8100, p=dense)
         assert O.choice_from_uniform(dense, u) == want
+
+
+def test_arena_games_match_reference():
+    """Arena gate (train.py:453-535) with stub models: per-game winner and length, totals."""
+    for t in G.arena_traces():
+        new, old = StubEvaluator(peaked=t["new_peaked"]), StubEvaluator(peaked=not t["new_peaked"])
+        new_wins = old_wins = draws = 0
+        for g in t["games"]:
+            new_is_red = g["game"] % 2 == 0
+            w, steps = O.arena_game(new.predict, old.predict, new_is_red, t["eval_simulations"], t["max_game_length"])
+            assert (w, steps) == (g["winner"], g["steps"]), (t["name"], g)
+            if w == 0:
+                draws += 1
+            elif (w == 1) == new_is_red:
+                new_wins += 1
+            else:
+                old_wins += 1
+        assert (new_wins, old_wins, draws) == (t["stats"]["new_wins"], t["stats"]["old_wins"], t["stats"]["draws"])

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
     uint16_t *pmoves = E.pmoves + (size_t)slot * XQ_MAXM;
     const double *rootP = E.rootP + (size_t)slot * XQ_MAXM;
     const int S = E.cfg.num_simulations;
-    const bool manual = E.cfg.manual_moves != 0;
+    const bool manual = E.cfg.manual_moves == 1;     // search only (MCTS.search parity / serving)
+    const bool arena = E.cfg.manual_moves == 2;      // evaluation games (train.py:453-535): T = 0, no opening, no samples
 
     int phase = __builtin_amdgcn_readfirstlane(gi[GI_PHASE]);
     if (phase == PH_IDLE || phase == PH_HOLD || phase == PH_WAIT_ROOT || phase == PH_WAIT_LEAF) return;
@@ -326,9 +327,9 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
             g_side = 1; g_mc = 0; g_nocap = 0;
             if (lane == 0) { gi[GI_RESIGN_N] = 0; st[ST_STARTED] += 1; }
             wave_sync();
-            const int R = E.cfg.random_opening_moves;
+            const int R = arena ? 0 : E.cfg.random_opening_moves;
             const int k = R > 0 ? (int)(draw_u64(E, slot, RNG_RANDINT, rng_ctr[RNG_RANDINT], st) % (uint64_t)(R + 1)) : 0;
-            rng_ctr[RNG_RANDINT] += 1;   // random.randint is called even when R == 0
+            if (!arena) rng_ctr[RNG_RANDINT] += 1;   // random.randint is called even when R == 0
             for (int i = 0; i < k; ++i) {
                 const int cnt = wave_movegen(L.root, g_side, L.mg, L.moves, &ovf);
                 if (cnt == 0) break;
@@ -353,7 +354,10 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
             int status = 0;
             const bool done = wave_game_over(L.root, L.rhist, g_side, g_mc, g_nocap, L.mg, L.moves, &cnt, &winner, &ovf);
             if (done) status = 1;
-            else if (!manual && g_mc >= E.cfg.max_game_length) {   // parallel_selfplay.py:79-89
+            else if (arena && g_mc >= E.cfg.max_game_length) {     // train.py:477,494-496: not over after max plies => draw
+                winner = 0;
+                status = 2;
+            } else if (!manual && !arena && g_mc >= E.cfg.max_game_length) {   // parallel_selfplay.py:79-89
                 int red, black;
                 wave_material(L.root, red, black);
                 const int diff = red - black;
@@ -374,9 +378,29 @@ __global__ __launch_bounds__(64) void k_select(Dev E, float *__restrict__ nn_in)
         // ---- phase == PH_SEARCH
         if (sims_done >= S) {
             if (manual) { phase = PH_HOLD; break; }
-            // ---- end of move: sample (parallel_selfplay.py:97-107), pi from visit counts (mcts.py:190-206)
             const int nch = __builtin_amdgcn_readfirstlane((int)(tM[0] & 0x3FFF));
             const int first = __builtin_amdgcn_readfirstlane(tC[0]);
+            if (arena) {
+                // MCTS.get_action(temperature=0) (mcts.py:166-174, 197-200): first maximum of the visit counts, move order
+                int bn = -1, bi = 0x7FFFFFFF;
+                for (int i = lane; i < nch; i += 64) {
+                    const int n = tN[first + i];
+                    if (n > bn) { bn = n; bi = i; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int on = __shfl_xor(bn, off), oi = __shfl_xor(bi, off);
+                    if (on > bn || (on == bn && oi < bi)) { bn = on; bi = oi; }
+                }
+                bi = __builtin_amdgcn_readfirstlane(bi);
+                const int action = __builtin_amdgcn_readfirstlane((int)tA[first + bi]);
+                wave_make_move(L.root, L.rhist, action, g_side, g_mc, g_nocap);
+                d_moves += 1;
+                state_dirty = true;
+                phase = PH_NEWPOS;
+                continue;
+            }
+            // ---- end of move: sample (parallel_selfplay.py:97-107), pi from visit counts (mcts.py:190-206)
             const bool late = g_mc >= E.cfg.temperature_threshold;
             const double inv_t = 1.0 / E.cfg.late_temperature;
             uint8_t *rec = E.stage + ((size_t)slot * E.stage_cap + (n_samples < E.stage_cap ? n_samples : E.stage_cap - 1)) * XQ_SAMPLE_BYTES;
@@ -545,7 +569,8 @@ __global__ __launch_bounds__(64) void k_expand(Dev E, const float *__restrict__ 
     const int32_t *path = E.path + (size_t)slot * E.path_cap;
     const uint16_t *pmoves = E.pmoves + (size_t)slot * XQ_MAXM;
     double *rootP = E.rootP + (size_t)slot * XQ_MAXM;
-    const bool manual = E.cfg.manual_moves != 0;
+    const bool manual = E.cfg.manual_moves == 1;
+    const bool arena = E.cfg.manual_moves == 2;
     const bool is_root = phase == PH_WAIT_ROOT;
     const double v_net = (double)value[slot];        // tensor.item(): float32 widened
     const int cnt = __builtin_amdgcn_readfirstlane(gi[GI_PCOUNT]);
@@ -557,7 +582,7 @@ __global__ __launch_bounds__(64) void k_expand(Dev E, const float *__restrict__ 
         const int side = gi[GI_SIDE];
         int fin = 0, fwinner = 0, freason = 0;
         // resign probe on the position after the move (parallel_selfplay.py:110-121)
-        if (!manual && E.cfg.enable_resign && gi[GI_NSAMP] > 10) {
+        if (!manual && !arena && E.cfg.enable_resign && gi[GI_NSAMP] > 10) {
             const int K = E.cfg.resign_check_steps;
             double *rh = E.resign + (size_t)slot * 16;
             int rn = gi[GI_RESIGN_N];
@@ -700,9 +725,9 @@ __global__ void k_init(Dev E) {
     if (slot >= E.cfg.n_games) return;
     int32_t *gi = E.gi + (size_t)slot * GI_N;
     for (int i = 0; i < GI_N; ++i) gi[i] = 0;
-    gi[GI_PHASE] = E.cfg.manual_moves ? PH_HOLD : PH_NEWGAME;
+    gi[GI_PHASE] = E.cfg.manual_moves == 1 ? PH_HOLD : PH_NEWGAME;
     gi[GI_SIDE] = 1;
-    if (E.cfg.start_stagger && !E.cfg.manual_moves)
+    if (E.cfg.start_stagger && E.cfg.manual_moves == 0)
         gi[GI_DELAY] = (int)(philox_u64(E.cfg.seed, (uint32_t)E.cfg.rank, (uint32_t)slot, 7u, 0u, 0u) % (uint64_t)(E.cfg.num_simulations + 1));
     unsigned long long *st = E.stats + (size_t)slot * ST_N;
     for (int i = 0; i < ST_N; ++i) st[i] = 0;

@@ -29,7 +29,7 @@ def make_config(n_games: int, num_simulations: int, *, c_puct: float = 1.5, temp
                 resign_threshold: float = -0.9, resign_check_steps: int = 5, add_noise: bool = True,
                 dirichlet_alpha: float = 0.3, noise_eps: float = 0.25, late_temperature: float = 0.3,
                 seed: int = 0, rank: int = 0, inject_len: int = 0, games_target: int = 0,
-                max_out_samples: int = 0, max_out_results: int = 0, manual_moves: bool = False,
+                max_out_samples: int = 0, max_out_results: int = 0, manual_moves: int = 0,
                 start_stagger: bool = False) -> hip.EngineConfig:
     """Defaults are the reference's TrainingConfig (training/train.py:55-111) and hard-coded constants
     (mcts.py:118-121, parallel_selfplay.py:92)."""
@@ -71,6 +71,10 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             hip.check(self.lib.xq_engine_init(C.byref(self.h), C.byref(cfg), base, self.workspace_bytes, inj_ptr,
                                               hip.stream_ptr(self.device)), "xq_engine_init")
+        # zero-copy int32 view of the per-slot state words (side to move of the REAL game in column 0, move_count 1,
+        # phase 3, simulations done 4): host-side policies such as the arena's model choice read it between stages
+        gi_off = int(self.h.p[2]) - int(self.ws.data_ptr())
+        self.slot_ints = self.ws[gi_off:gi_off + self.G * 32 * 4].view(torch.int32).view(self.G, 32)
         self.steps = 0
 
     # ---- the three stages of a step --------------------------------------------------------------------
