@@ -1,6 +1,6 @@
 // xq_batch.hip -- stateless batched rules kernels behind the B1 plug point (include/xq_hip.h).
-// One 64-lane wavefront per position, one wavefront per workgroup (so LDS is private to the wave and the
-// workgroup barrier is a wave fence).  Integer/LDS-bound work: 90 bytes in, <= 2*L bytes out per position.
+// One 64-lane wavefront per position, four positions per 256-thread workgroup (LDS carved per wave, no workgroup
+// barrier: lane-to-lane traffic of one wave through LDS only needs program order, see xq_rules.cuh).  Integer/LDS-bound work: 90 bytes in, <= 2*L bytes out per position.
 #include "xq_common.h"
 #include "xq_rules.cuh"
 
@@ -12,23 +12,30 @@ thread_local hipError_t g_last_error = hipSuccess;
 
 using namespace xq;
 
+// four positions per 256-thread workgroup, one per wave; LDS carved per wave, no workgroup barrier (see xq_rules.cuh)
+constexpr int WPW = 4;
+#define XQ_WAVE_ITEM(n)                                             \
+    const int wv = (int)(threadIdx.x >> 6);                         \
+    const int i = blockIdx.x * WPW + wv;                            \
+    if (i >= (n)) return;
+
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_movegen(const int8_t *__restrict__ boards, const int8_t *__restrict__ side,
+__global__ __launch_bounds__(64 * WPW) void k_movegen(const int8_t *__restrict__ boards, const int8_t *__restrict__ side,
                                                 int n, uint16_t *__restrict__ moves, uint16_t *__restrict__ counts,
                                                 uint8_t *__restrict__ in_chk, uint8_t *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) int8_t s_board[XQ_BS];
-    __shared__ MoveGenLds s_mg;
-    __shared__ uint16_t s_out[XQ_MAXM];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+    __shared__ __attribute__((aligned(16))) int8_t s_boards[WPW][XQ_BS];
+    __shared__ MoveGenLds s_mgs[WPW];
+    __shared__ uint16_t s_outs[WPW][XQ_MAXM];
+    XQ_WAVE_ITEM(n)
+    int8_t *s_board = s_boards[wv];
     const int lane = lane_id();
     wave_load_board(boards + (size_t)i * 90, s_board);
     wave_sync();
     const int player = side[i];
     int ovf = 0;
-    const int cnt = wave_movegen(s_board, player, s_mg, s_out, &ovf);
+    const int cnt = wave_movegen(s_board, player, s_mgs[wv], s_outs[wv], &ovf);
     uint16_t *dst = moves + (size_t)i * XQ_MAXM;
-    for (int j = lane; j < cnt; j += 64) dst[j] = s_out[j];
+    for (int j = lane; j < cnt; j += 64) dst[j] = s_outs[wv][j];
     if (lane == 0) {
         counts[i] = (uint16_t)cnt;
         if (in_chk) in_chk[i] = in_check(s_board, player) ? 1 : 0;
@@ -36,10 +43,10 @@ __global__ __launch_bounds__(64) void k_movegen(const int8_t *__restrict__ board
     }
 }
 
-__global__ __launch_bounds__(64) void k_attack_map(const int8_t *__restrict__ boards, int n, uint8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) int8_t s_board[XQ_BS];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(64 * WPW) void k_attack_map(const int8_t *__restrict__ boards, int n, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) int8_t s_boards[WPW][XQ_BS];
+    XQ_WAVE_ITEM(n)
+    int8_t *s_board = s_boards[wv];
     const int lane = lane_id();
     wave_load_board(boards + (size_t)i * 90, s_board);
     wave_sync();
@@ -51,10 +58,10 @@ __global__ __launch_bounds__(64) void k_attack_map(const int8_t *__restrict__ bo
     }
 }
 
-__global__ __launch_bounds__(64) void k_find_king(const int8_t *__restrict__ boards, int n, int16_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) int8_t s_board[XQ_BS];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(64 * WPW) void k_find_king(const int8_t *__restrict__ boards, int n, int16_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) int8_t s_boards[WPW][XQ_BS];
+    XQ_WAVE_ITEM(n)
+    int8_t *s_board = s_boards[wv];
     wave_load_board(boards + (size_t)i * 90, s_board);
     wave_sync();
     const VMove none{-1, -1, 0};
@@ -62,20 +69,20 @@ __global__ __launch_bounds__(64) void k_find_king(const int8_t *__restrict__ boa
     if (lane < 2) out[(size_t)i * 2 + lane] = (int16_t)find_king(s_board, none, lane == 0 ? 1 : -1);
 }
 
-__global__ __launch_bounds__(64) void k_encode(const int8_t *__restrict__ boards, const int8_t *__restrict__ side, int n,
+__global__ __launch_bounds__(64 * WPW) void k_encode(const int8_t *__restrict__ boards, const int8_t *__restrict__ side, int n,
                                                float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) int8_t s_board[XQ_BS];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+    __shared__ __attribute__((aligned(16))) int8_t s_boards[WPW][XQ_BS];
+    XQ_WAVE_ITEM(n)
+    int8_t *s_board = s_boards[wv];
     wave_load_board(boards + (size_t)i * 90, s_board);
     wave_sync();
     wave_encode(s_board, side[i], out + (size_t)i * XQ_STATE_FLOATS);
 }
 
-__global__ __launch_bounds__(64) void k_material(const int8_t *__restrict__ boards, int n, int32_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) int8_t s_board[XQ_BS];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(64 * WPW) void k_material(const int8_t *__restrict__ boards, int n, int32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) int8_t s_boards[WPW][XQ_BS];
+    XQ_WAVE_ITEM(n)
+    int8_t *s_board = s_boards[wv];
     wave_load_board(boards + (size_t)i * 90, s_board);
     wave_sync();
     int red, black;
@@ -102,15 +109,15 @@ __global__ void k_apply_moves(const int8_t *__restrict__ boards, const int8_t *_
 }
 
 // game.py:565-616 for independent states; hist = last min(12,mc) pre-move boards, oldest first
-__global__ __launch_bounds__(64) void k_game_over(const int8_t *__restrict__ boards, const int8_t *__restrict__ side,
+__global__ __launch_bounds__(64 * WPW) void k_game_over(const int8_t *__restrict__ boards, const int8_t *__restrict__ side,
                                                   const int32_t *__restrict__ move_count,
                                                   const int32_t *__restrict__ no_capture, const int8_t *__restrict__ hist,
                                                   int n, int8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) int8_t s_board[XQ_BS];
-    __shared__ MoveGenLds s_mg;
-    __shared__ uint16_t s_out[XQ_MAXM];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+    __shared__ __attribute__((aligned(16))) int8_t s_boards[WPW][XQ_BS];
+    __shared__ MoveGenLds s_mgs[WPW];
+    __shared__ uint16_t s_outs[WPW][XQ_MAXM];
+    XQ_WAVE_ITEM(n)
+    int8_t *s_board = s_boards[wv];
     const int lane = lane_id();
     wave_load_board(boards + (size_t)i * 90, s_board);
     wave_sync();
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(64) void k_game_over(const int8_t *__restrict__ boa
     else if (find_king(s_board, none, -1) < 0) { done = 1; winner = 1; }
     else {
         int ovf = 0;
-        const int cnt = wave_movegen(s_board, player, s_mg, s_out, &ovf);
+        const int cnt = wave_movegen(s_board, player, s_mgs[wv], s_outs[wv], &ovf);
         if (cnt == 0) { done = 1; winner = -player; }
         else if (nc >= 120) { done = 1; winner = 0; }
         else if (mc >= 200) {
@@ -155,7 +162,7 @@ int xq_movegen_batch(const int8_t *dev_boards, const int8_t *dev_side, int n, ui
                      uint8_t *dev_in_check, uint8_t *dev_status, void *stream) {
     if (n < 0 || (n > 0 && (!dev_boards || !dev_side || !dev_moves || !dev_counts))) return XQ_ERR_ARG;
     if (n == 0) return XQ_OK;
-    hipLaunchKernelGGL(k_movegen, dim3(n), dim3(64), 0, (hipStream_t)stream, dev_boards, dev_side, n, dev_moves,
+    hipLaunchKernelGGL(k_movegen, dim3((n + WPW - 1) / WPW), dim3(64 * WPW), 0, (hipStream_t)stream, dev_boards, dev_side, n, dev_moves,
                        dev_counts, dev_in_check, dev_status);
     return launch_status();
 }
@@ -163,28 +170,28 @@ int xq_movegen_batch(const int8_t *dev_boards, const int8_t *dev_side, int n, ui
 int xq_attack_map_batch(const int8_t *dev_boards, int n, uint8_t *dev_out, void *stream) {
     if (n < 0 || (n > 0 && (!dev_boards || !dev_out))) return XQ_ERR_ARG;
     if (n == 0) return XQ_OK;
-    hipLaunchKernelGGL(k_attack_map, dim3(n), dim3(64), 0, (hipStream_t)stream, dev_boards, n, dev_out);
+    hipLaunchKernelGGL(k_attack_map, dim3((n + WPW - 1) / WPW), dim3(64 * WPW), 0, (hipStream_t)stream, dev_boards, n, dev_out);
     return launch_status();
 }
 
 int xq_find_king_batch(const int8_t *dev_boards, int n, int16_t *dev_out, void *stream) {
     if (n < 0 || (n > 0 && (!dev_boards || !dev_out))) return XQ_ERR_ARG;
     if (n == 0) return XQ_OK;
-    hipLaunchKernelGGL(k_find_king, dim3(n), dim3(64), 0, (hipStream_t)stream, dev_boards, n, dev_out);
+    hipLaunchKernelGGL(k_find_king, dim3((n + WPW - 1) / WPW), dim3(64 * WPW), 0, (hipStream_t)stream, dev_boards, n, dev_out);
     return launch_status();
 }
 
 int xq_encode_batch(const int8_t *dev_boards, const int8_t *dev_side, int n, float *dev_out, void *stream) {
     if (n < 0 || (n > 0 && (!dev_boards || !dev_side || !dev_out))) return XQ_ERR_ARG;
     if (n == 0) return XQ_OK;
-    hipLaunchKernelGGL(k_encode, dim3(n), dim3(64), 0, (hipStream_t)stream, dev_boards, dev_side, n, dev_out);
+    hipLaunchKernelGGL(k_encode, dim3((n + WPW - 1) / WPW), dim3(64 * WPW), 0, (hipStream_t)stream, dev_boards, dev_side, n, dev_out);
     return launch_status();
 }
 
 int xq_material_batch(const int8_t *dev_boards, int n, int32_t *dev_out, void *stream) {
     if (n < 0 || (n > 0 && (!dev_boards || !dev_out))) return XQ_ERR_ARG;
     if (n == 0) return XQ_OK;
-    hipLaunchKernelGGL(k_material, dim3(n), dim3(64), 0, (hipStream_t)stream, dev_boards, n, dev_out);
+    hipLaunchKernelGGL(k_material, dim3((n + WPW - 1) / WPW), dim3(64 * WPW), 0, (hipStream_t)stream, dev_boards, n, dev_out);
     return launch_status();
 }
 
@@ -205,7 +212,7 @@ int xq_game_over_batch(const int8_t *dev_boards, const int8_t *dev_side, const i
     if (n < 0 || (n > 0 && (!dev_boards || !dev_side || !dev_move_count || !dev_no_capture || !dev_hist || !dev_out)))
         return XQ_ERR_ARG;
     if (n == 0) return XQ_OK;
-    hipLaunchKernelGGL(k_game_over, dim3(n), dim3(64), 0, (hipStream_t)stream, dev_boards, dev_side, dev_move_count,
+    hipLaunchKernelGGL(k_game_over, dim3((n + WPW - 1) / WPW), dim3(64 * WPW), 0, (hipStream_t)stream, dev_boards, dev_side, dev_move_count,
                        dev_no_capture, dev_hist, n, dev_out);
     return launch_status();
 }
