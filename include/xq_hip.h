@@ -207,6 +207,16 @@ size_t xq_wino_weight_bytes(int channels);
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
                     float *dev_y, int batch, int channels, int relu, void *stream);
 
+/* =====================================================================================
+ * Next row (section 8f.1) -- training-batch materialisation.  Replaces SelfPlayDataset.__getitem__ + augment_data
+ * (training/train.py:114-151) and _augment_data (training/parallel_selfplay.py:137-151) for a batch drawn from a
+ * device-resident buffer of compact samples: output j is sample dev_index[j] (mirrored left-right when dev_flip[j]):
+ * dev_states[j] float32[15][10][9], dev_pi[j] float32[8100] (visits^(1/T) normalised in float64, cast to float32),
+ * dev_z[j] float32.  dev_samples: xq_sample[...] in device memory.
+ * ===================================================================================== */
+int xq_samples_to_batch(const void *dev_samples, const int32_t *dev_index, const uint8_t *dev_flip, int n,
+                        double late_temperature, float *dev_states, float *dev_pi, float *dev_z, void *stream);
+
 /* Finished training sample (compact form of the reference's (state, pi, z) tuple,
  * parallel_selfplay.py:97-99,123-132; dense pi / planes / flip augmentation materialise on the consumer). */
 typedef struct xq_sample {

@@ -18,6 +18,7 @@ Fixtures written (all small):
   game_traces.json      reference _play_one_game with every random draw injected (tests/draws.py)
   flip_perm.npy         8100-entry action permutation of _augment_data
   arena_traces.json     reference AlphaZeroTrainer._serial_evaluate with stub models: per-game winner/steps, totals
+  train_trace.json      reference AlphaZeroTrainer.train_network on a recorded game's augmented samples (fixed batch order)
   nn_golden.npz         reference XiangqiNet outputs for generator weights (xiangqi-alphazero_amd/weights.py)
 """
 import argparse
@@ -524,13 +525,80 @@ def gen_arena():
     json.dump(out, open(os.path.join(HERE, "arena_traces.json"), "w"))
 
 
+def gen_train():
+    """Reference AlphaZeroTrainer.train_network (train.py:376-447) run unbound on a stand-in `self`: replay buffer =
+    the reference's own _augment_data of a recorded stub game, 16x1 net with generator weights, DataLoader forced to
+    shuffle=False so the batch order is defined.  Records the returned stats and a few weights after the call."""
+    import types
+    from collections import deque
+    import torch
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        import train as ref_train                      # reference
+    finally:
+        os.chdir(cwd)
+    import parallel_selfplay as ref_sp
+    import model as ref_model
+    torch.set_num_threads(4)
+    W = _load_weights_mod()
+
+    class Cfg:
+        pass
+
+    t = [x for x in json.load(open(os.path.join(HERE, "game_traces.json"))) if x["name"] == "maxlen"][0]
+    cfg = Cfg()
+    for k, v in t["cfg"].items():
+        setattr(cfg, k, v)
+    d = Draws(t["seed"])
+    saved = (random.randint, random.choice, np.random.dirichlet, np.random.choice)
+    random.randint = lambda lo, hi: d.randint(lo, hi)
+    random.choice = lambda seq: seq[d.choice_index(len(seq))]
+    np.random.dirichlet = lambda alpha: d.dirichlet(len(alpha))
+
+    def choice(n, p=None):
+        cdf = np.asarray(p, dtype=np.float64).cumsum()
+        cdf /= cdf[-1]
+        return int(cdf.searchsorted(d.uniform(), side="right"))
+
+    np.random.choice = choice
+    try:
+        data, winner, steps = ref_sp._play_one_game(StubEvaluator(peaked=True), cfg, "cpu")
+    finally:
+        random.randint, random.choice, np.random.dirichlet, np.random.choice = saved
+    aug = ref_sp._augment_data(data)
+
+    net = ref_model.XiangqiNet(num_channels=16, num_res_blocks=1)
+    net.load_state_dict(W.make_state_dict(16, 1, seed=3))
+    tc = types.SimpleNamespace(min_buffer_size=10, num_epochs=2, batch_size=20)
+    opt = torch.optim.Adam(net.parameters(), lr=0.002, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1, 80], gamma=0.1)
+    fake = types.SimpleNamespace(config=tc, replay_buffer=deque(aug, maxlen=50000), current_model=net, optimizer=opt,
+                                 scheduler=sch, device="cpu")
+    real_loader = ref_train.DataLoader
+    ref_train.DataLoader = lambda ds, **kw: real_loader(ds, **{**kw, "shuffle": False})
+    try:
+        stats = ref_train.AlphaZeroTrainer.train_network(fake)
+    finally:
+        ref_train.DataLoader = real_loader
+    sd = net.state_dict()
+    probe = {k: [float(x) for x in sd[k].flatten()[:8].double()] for k in
+             ("input_conv.0.weight", "res_blocks.0.conv2.weight", "policy_head.4.bias", "value_head.6.weight",
+              "input_conv.1.running_mean", "value_head.1.running_var")}
+    out = dict(game="maxlen", n_samples=len(aug), net=[16, 1], seed=3, num_epochs=2, batch_size=20, lr=0.002,
+               weight_decay=1e-4, milestones=[1, 80], gamma=0.1, stats={k: float(v) for k, v in stats.items()},
+               probe=probe, num_batches_tracked=int(sd["input_conv.1.num_batches_tracked"]))
+    json.dump(out, open(os.path.join(HERE, "train_trace.json"), "w"))
+    print("train", stats)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--perft5", action="store_true")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     steps = dict(perft=lambda: gen_perft(args.perft5), corpus=gen_corpus, crafted=gen_crafted,
-                 mcts=gen_mcts_traces, games=gen_game_traces, nn=gen_nn, arena=gen_arena)
+                 mcts=gen_mcts_traces, games=gen_game_traces, nn=gen_nn, arena=gen_arena, train=gen_train)
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

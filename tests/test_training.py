@@ -1,0 +1,132 @@
+"""Next rows: train step on the device-resident compact buffer, checkpoint round trip."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as G
+from test_host_logic import _oracle_game_as_compact
+
+REF = "/root/reference/training"
+
+
+def _trace():
+    return json.load(open(os.path.join(G.GOLDEN, "train_trace.json")))
+
+
+@pytest.mark.gpu
+def test_batch_materialisation_matches_dense_adapter():
+    """xq_samples_to_batch == the reference-schema adapter (planes, dense pi incl. mirror, z) for every logical sample."""
+    import torch
+    from xiangqi_alphazero_amd import training
+    from xiangqi_alphazero_amd.sample_format import to_reference_tuples
+    for t in G.game_traces()[:2]:
+        arr, res = _oracle_game_as_compact(t)
+        data, _ = to_reference_tuples(arr, res, augment=True)
+        buf = training.ReplayBuffer(50000)
+        buf.extend(arr)
+        assert len(buf) == len(data)
+        states, pi, z = buf.batch(torch.arange(len(data)))
+        states, pi, z = states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+        for j, (s, p, zz) in enumerate(data):
+            np.testing.assert_array_equal(states[j], s)
+            assert z[j, 0] == zz
+            assert np.array_equal(np.nonzero(pi[j])[0], np.nonzero(p)[0])
+            np.testing.assert_allclose(pi[j], p.astype(np.float32), rtol=2e-7, atol=0)
+
+
+@pytest.mark.gpu
+def test_replay_buffer_is_fifo_like_the_reference_deque():
+    import torch
+    from xiangqi_alphazero_amd import training
+    arr, _ = _oracle_game_as_compact(G.game_traces()[1])
+    buf = training.ReplayBuffer(max_size=20)            # 10 records
+    buf.extend(arr[:7]); buf.extend(arr[7:16])
+    assert len(buf) == 20
+    st, _, _ = buf.batch(torch.tensor([0, 18]))
+    from xiangqi_alphazero_amd.sample_format import encode_planes
+    np.testing.assert_array_equal(st[0].cpu().numpy(), encode_planes(arr[6]["board"], int(arr[6]["side"])))
+    np.testing.assert_array_equal(st[1].cpu().numpy(), encode_planes(arr[15]["board"], int(arr[15]["side"])))
+
+
+@pytest.mark.gpu
+def test_train_network_matches_reference_trace():
+    """Same data, weights, optimiser and batch order as the reference's train_network run recorded in the fixture:
+    losses within 1e-4 relative; probed weights within 1e-4 absolute -- they move by up to 1.2e-2 in the six Adam steps
+    (lr 2e-3) and Adam's normalised update amplifies last-bit gradient differences between GPU and CPU kernels."""
+    import types
+    import torch
+    from xiangqi_alphazero_amd import model, training, weights
+    t = _trace()
+    game = [x for x in G.game_traces() if x["name"] == t["game"]][0]
+    arr, _ = _oracle_game_as_compact(game)
+    buf = training.ReplayBuffer(50000)
+    buf.extend(arr)
+    assert len(buf) == t["n_samples"]
+    net = model.XiangqiNet(*t["net"])
+    net.load_state_dict(weights.make_state_dict(*t["net"], seed=t["seed"]))
+    net = net.cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=t["lr"], weight_decay=t["weight_decay"])
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=t["milestones"], gamma=t["gamma"])
+    cfg = types.SimpleNamespace(min_buffer_size=10, num_epochs=t["num_epochs"], batch_size=t["batch_size"])
+    stats = training.train_network(net, opt, sch, buf, cfg, shuffle=False)
+    for k in ("policy_loss", "value_loss", "total_loss", "learning_rate"):
+        assert abs(stats[k] - t["stats"][k]) <= 1e-4 * abs(t["stats"][k]) + 1e-7, (k, stats[k], t["stats"][k])
+    sd = net.state_dict()
+    assert int(sd["input_conv.1.num_batches_tracked"]) == t["num_batches_tracked"]
+    for k, want in t["probe"].items():
+        np.testing.assert_allclose(sd[k].flatten()[:8].double().cpu().numpy(), want, rtol=0, atol=1e-4, err_msg=k)
+    assert training.train_network(net, opt, sch, training.ReplayBuffer(100), cfg) == {}     # below min_buffer_size
+
+
+def test_checkpoint_files_have_the_reference_layout(tmp_path):
+    import torch
+    from xiangqi_alphazero_amd import model, training, weights
+    cur, best = model.XiangqiNet(16, 1), model.XiangqiNet(16, 1)
+    cur.load_state_dict(weights.make_state_dict(16, 1, seed=1)); best.load_state_dict(weights.make_state_dict(16, 1, seed=2))
+    opt = torch.optim.Adam(cur.parameters(), lr=0.002, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[50, 80], gamma=0.1)
+    path = training.save_checkpoint(str(tmp_path), 7, cur, best, opt, sch, total_games=123, is_best=True)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"iteration", "model_state_dict", "best_model_state_dict", "optimizer_state_dict",
+                       "scheduler_state_dict", "config", "total_games"}                      # train.py:539-550
+    bm = torch.load(os.path.join(tmp_path, "best_model.pt"), weights_only=True)
+    assert set(bm) == {"model_state_dict", "config", "iteration", "total_games"} and bm["config"] == {"num_channels": 16, "num_res_blocks": 1}
+    c2, b2 = model.XiangqiNet(16, 1), model.XiangqiNet(16, 1)
+    info = training.load_checkpoint(path, c2, b2, torch.optim.Adam(c2.parameters()), None)
+    assert info["iteration"] == 7 and info["total_games"] == 123
+    assert all(torch.equal(a, b) for a, b in zip(c2.state_dict().values(), cur.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(b2.state_dict().values(), best.state_dict().values()))
+    assert torch.equal(model.load_reference_checkpoint(os.path.join(tmp_path, "best_model.pt")).state_dict()["policy_head.4.bias"],
+                       best.state_dict()["policy_head.4.bias"])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_checkpoint_loads_with_the_reference_loader(tmp_path):
+    """A file written here is read by the reference's own AlphaZeroTrainer.load_checkpoint (train.py:569-579)."""
+    import sys
+    import types
+    import torch
+    from xiangqi_alphazero_amd import model, training, weights
+    sys.dont_write_bytecode = True
+    cur, best = model.XiangqiNet(16, 1), model.XiangqiNet(16, 1)
+    cur.load_state_dict(weights.make_state_dict(16, 1, seed=5)); best.load_state_dict(weights.make_state_dict(16, 1, seed=6))
+    opt = torch.optim.Adam(cur.parameters(), lr=0.002, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[50, 80], gamma=0.1)
+    path = training.save_checkpoint(str(tmp_path), 3, cur, best, opt, sch, total_games=40)
+    sys.path[:0] = [REF, os.path.join(G.GOLDEN, "..", "..", "oracle", "_ref")]
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))                          # the reference opens 'training.log' in the cwd at import
+    try:
+        import train as ref_train
+        import model as ref_model
+    finally:
+        os.chdir(cwd)
+    rc, rb = ref_model.XiangqiNet(num_channels=16, num_res_blocks=1), ref_model.XiangqiNet(num_channels=16, num_res_blocks=1)
+    ro = torch.optim.Adam(rc.parameters(), lr=0.002, weight_decay=1e-4)
+    fake = types.SimpleNamespace(device="cpu", current_model=rc, best_model=rb, optimizer=ro,
+                                 scheduler=torch.optim.lr_scheduler.MultiStepLR(ro, milestones=[50, 80], gamma=0.1))
+    ref_train.AlphaZeroTrainer.load_checkpoint(fake, path)
+    assert fake.iteration == 3 and fake.total_games == 40
+    assert all(torch.equal(a, b) for a, b in zip(rc.state_dict().values(), cur.state_dict().values()))
