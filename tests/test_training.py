@@ -130,3 +130,30 @@ def test_checkpoint_loads_with_the_reference_loader(tmp_path):
     ref_train.AlphaZeroTrainer.load_checkpoint(fake, path)
     assert fake.iteration == 3 and fake.total_games == 40
     assert all(torch.equal(a, b) for a, b in zip(rc.state_dict().values(), cur.state_dict().values()))
+
+
+@pytest.mark.gpu
+def test_full_loop_two_iterations(tmp_path):
+    """AlphaZeroTrainer.train() order on the engine: self-play -> train -> arena gate (iteration 2) -> checkpoint."""
+    import types
+    import torch
+    from xiangqi_alphazero_amd import train_loop
+    cfg = types.SimpleNamespace(
+        num_channels=64, num_res_blocks=1, num_simulations=8, c_puct=1.5, temperature_threshold=10, num_games_per_iter=16,
+        max_game_length=30, resign_threshold=-0.9, resign_check_steps=5, enable_resign=True, random_opening_moves=4,
+        num_iterations=2, batch_size=64, num_epochs=1, learning_rate=0.002, weight_decay=1e-4, lr_milestones=[50, 80],
+        lr_gamma=0.1, max_buffer_size=50000, min_buffer_size=100, eval_games=4, eval_win_rate=0.55, eval_simulations=8,
+        checkpoint_dir=str(tmp_path), save_interval=2)
+    loop = train_loop.AlphaZeroLoop(cfg, "cuda", seed=3)
+    stats = loop.train()
+    assert [s["iteration"] for s in stats] == [1, 2]
+    assert stats[0]["self_play"]["games"] == 16 and stats[0]["self_play"]["mode"] == "hip"
+    assert stats[0]["training"]["policy_loss"] > 0 and stats[1]["training"]["policy_loss"] < stats[0]["training"]["policy_loss"] + 1.0
+    assert stats[0]["evaluation"] == {} and set(stats[1]["evaluation"]) == {"new_wins", "old_wins", "draws", "win_rate", "model_updated"}
+    assert os.path.exists(tmp_path / "checkpoint_iter2.pt") and os.path.exists(tmp_path / "best_model.pt")
+    saved = json.load(open(tmp_path / "training_stats.json"))
+    assert len(saved) == 2 and saved[1]["self_play"]["buffer_size"] == len(loop.buffer)
+    ev = stats[1]["evaluation"]
+    same = all(torch.equal(a, b) for a, b in zip(loop.current_model.state_dict().values(), loop.best_model.state_dict().values()))
+    assert same                                        # promoted or reverted: both leave current == best (train.py:525-533)
+    assert ev["new_wins"] + ev["old_wins"] + ev["draws"] == 4
