@@ -207,6 +207,12 @@ size_t xq_wino_weight_bytes(int channels);
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
                     float *dev_y, int batch, int channels, int relu, void *stream);
 
+/* Diagnostic twin of xq_wino_conv3x3 (perf analysis only, tests/perf_conv_stamps.py): same computation, plus per
+ * workgroup 100 MHz timestamps {start, after prologue, after main loop, end, XCC id} and the HW_ID of each of its 8
+ * waves into dev_stamps[grid][16] (uint64), grid = 8 * ceil(ceil(batch*25/64) / (8 / (channels/64))). */
+int xq_wino_conv3x3_dbg(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
+                        float *dev_y, int batch, int channels, int relu, unsigned long long *dev_stamps, void *stream);
+
 /* =====================================================================================
  * Next row (section 8f.1) -- training-batch materialisation.  Replaces SelfPlayDataset.__getitem__ + augment_data
  * (training/train.py:114-151) and _augment_data (training/parallel_selfplay.py:137-151) for a batch drawn from a

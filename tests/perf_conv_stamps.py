@@ -13,7 +13,6 @@ y = torch.empty_like(x)
 grid = 12800
 st = torch.zeros(grid * 16, dtype=torch.int64, device="cuda")
 L = hip.lib()
-L.xq_wino_conv3x3_dbg.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 2
 for _ in range(3):
     rc = L.xq_wino_conv3x3_dbg(x.data_ptr(), u.data_ptr(), bias.data_ptr(), res.data_ptr(), y.data_ptr(), B, Cc, 1, st.data_ptr(), hip.stream_ptr(x.device))
     assert rc == 0
