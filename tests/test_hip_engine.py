@@ -282,3 +282,28 @@ def test_arena_gate_matches_reference(eng_mod):
         for r, g in zip(res, t["games"]):
             assert (int(r["winner"]), int(r["steps"])) == (g["winner"], g["steps"]), (t["name"], g)
             assert int(r["n_samples"]) == 0
+
+
+def test_mcts_shim_has_the_reference_call_shape(eng_mod):
+    """`MCTS(model, num_simulations, c_puct).search(game, T, add_noise)` / `.get_action` (mcts.py:76-174) on the engine,
+    with a duck-typed game object carrying the reference's attribute names."""
+    import types
+    import torch
+    from xiangqi_alphazero_amd import mcts as M
+    t = [x for x in G.mcts_traces() if x["sims"] == 100 and not x["noisy"] and x["stub"] == "peaked"][3]
+    g = _replay(t["actions"])
+    game = types.SimpleNamespace(board=g.board.copy(), current_player=g.current_player, move_count=g.move_count,
+                                 no_capture_count=g.no_capture_count, history=[bytes(h) for h in g.history()])
+
+    def stub(x):                                   # batched evaluator returning LOGITS whose softmax is the stub's probs
+        p, v = _stub_batch(x.cpu().numpy(), [True] * x.shape[0])
+        return torch.log(torch.from_numpy(p).cuda()), torch.from_numpy(v).cuda()
+
+    m = M.MCTS(stub, num_simulations=100, c_puct=1.5)
+    pi = m.search(game, temperature=1.0, add_noise=False)
+    assert pi.shape == (8100,) and pi.dtype == np.float64 and abs(pi.sum() - 1.0) < 1e-12
+    want = np.zeros(8100); want[t["root_actions"]] = t["visits"]; want /= want.sum()
+    # log/softmax round trip perturbs the priors by ~1e-7: visit counts agree except on PUCT near-ties
+    assert np.abs(pi - want).sum() <= 0.04
+    a = m.get_action(game, temperature=0)
+    assert pi[a] >= pi.max() - 0.02
