@@ -80,6 +80,55 @@ __global__ __launch_bounds__(512, 2) void kmix(float *out, const float *g, int i
     if (s == 1234.5f) out[tid] = s;
 }
 
+// 16x16x4 twin of kmix (two MFMAs of half the size per slot: same FLOPs, half the accumulator write-back)
+// MIX bits: 1 = 8 conflict-free ds_read_b128, 2 = 8 four-way-conflicted ds_read_b128, 4 = 4 ds_write_b128,
+// 8 = 4 global_load_dwordx4 (L2-resident), 16 = 32 VALU, 32 = __syncthreads per iteration, 64 = 3 more global loads + 3 ds_write (staging)
+template <int MIX>
+__global__ __launch_bounds__(512, 2) void kmix16(float *out, const float *g, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    float a = tid * 0.001f, b = 1.0f + lane * 0.01f;
+    f32x4 v = {a, b, a, b}, t = {0, 0, 0, 0}, u[4] = {v, v, v, v}, xs[3] = {v, v, v};
+    const char *lp = lds + lane * 16 + wave * 1024;
+    const char *lc = lds + 65536 + (lane & 31) * 256 + (lane >> 5) * 16 + wave * 32;   // 256-B stride: 16 lanes of a b128 group on 1 bank quad... 4+ way
+    char *lw = lds + 131072 - 8192 + lane * 16 + wave * 1024;
+    const float *gp = g + (size_t)blockIdx.x % 8 * 262144 + wave * 4096 + lane * 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3].x + a, b, acc[i], 0, 0, 0);
+            acc[(i + 16) & 31] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3].y + a, b, acc[(i + 16) & 31], 0, 0, 0);
+            if ((MIX & 1) && (i & 3) == 0) t += *(const f32x4 *)(lp + (i >> 2) * 8192);
+            if ((MIX & 2) && (i & 3) == 1) t += *(const f32x4 *)(lc + (i >> 2) * 4096 % 32768);
+            if ((MIX & 4) && (i & 7) == 6) *(f32x4 *)(lw + (i >> 3) * 65536 % 8192) = t;
+            if ((MIX & 8) && (i & 7) == 2) u[i >> 3] = *(const f32x4 *)(gp + ((it * 4 + (i >> 3)) & 63) * 1024);
+            if ((MIX & 64) && (i & 7) == 5 && i < 24) xs[i >> 3] = *(const f32x4 *)(gp + 65536 + ((it * 4 + (i >> 3)) & 63) * 1024);
+            if ((MIX & 64) && (i & 7) == 7 && i < 24) *(f32x4 *)(lw - 16384 + (i >> 3) * 1024) = xs[i >> 3];
+            if (MIX & 16) v.x = v.x * b + a;
+        }
+        if (MIX & 32) __syncthreads();
+    }
+    float s = v.x + v.y + v.z + v.w + t.x + t.y + t.z + t.w + u[0].x + u[1].y + u[2].z + u[3].w + xs[0].x + xs[1].x + xs[2].x;
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 1234.5f) out[tid] = s;
+}
+
+template <int MIX>
+void runmix16(const char *name, float *d, const float *g) {
+    hipFuncSetAttribute((const void *)kmix16<MIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
+    const int iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kmix16<MIX><<<256, 512, 159744>>>(d, g, 10);
+    hipEventRecord(e0);
+    kmix16<MIX><<<256, 512, 159744>>>(d, g, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double tf = (double)256 * 8 * iters * 64 * 2048 / (ms * 1e-3) / 1e12;
+    printf("16x16x4 mix %3d %-42s %8.3f ms  %6.1f TFLOP/s  cycles/iter/SIMD@2.4GHz %.0f\n", MIX, name, ms, tf, ms * 1e-3 * 2.4e9 / iters);
+}
+
 template <int MIX>
 void runmix(const char *name, float *d, const float *g) {
     hipFuncSetAttribute((const void *)kmix<MIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
@@ -135,5 +184,12 @@ int main() {
     runmix<1 + 2 + 4 + 16 + 32>("LDS+VALU mix + barrier", d, g);
     runmix<1 + 2 + 4 + 8 + 16 + 32>("full chunk mix (no staging)", d, g);
     runmix<1 + 2 + 4 + 8 + 16 + 32 + 64>("full chunk mix + staging", d, g);
+    runmix16<0>("MFMA only (both waves)", d, g);
+    runmix16<1>("+8 ds_read_b128", d, g);
+    runmix16<8>("+4 global_load_dwordx4", d, g);
+    runmix16<16>("+32 VALU", d, g);
+    runmix16<1 + 2 + 4 + 16>("LDS+VALU mix, no barrier", d, g);
+    runmix16<1 + 4 + 8 + 16 + 32>("kernel-like mix: 8 reads, 4 writes, 4 loads, 32 VALU, barrier", d, g);
+    runmix<1 + 4 + 8 + 16 + 32>("(32x32x2) kernel-like mix: same", d, g);
     return 0;
 }
