@@ -147,16 +147,13 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
         *(f32x4 *)(dst + 2 * 2 * TILES * 16) = w[2] - w[1];
         *(f32x4 *)(dst + 3 * 2 * TILES * 16) = w[1] - w[3];
     };
-    // One chunk of work for a wave: 32 MFMAs on V[buf] x u, with the B^T d B transform of chunk `nchunk` into
-    // V[buf^1] threaded between them.  A 64-cycle fp32 MFMA leaves ~56 issue cycles before the pipe takes the next
-    // one; ~4 vector/LDS instructions per MFMA ride in that shadow.  Clustered (8 MFMAs, then 25 VALU) they do
-    // not: the cluster delays the next MFMA.  sched_group_barrier pins the interleave.
-    // One chunk of work for a wave: 32 MFMAs on V[buf] x u, with the B^T d B transform of chunk `nchunk` into
-    // V[buf^1] threaded between them.  On gfx950 the fp32 MFMA runs at exactly the fp32 VALU rate and, measured here,
-    // every other vector instruction a SIMD issues adds its issue time to the MFMA stream (no co-execution as with
-    // the bf16 matrix core): the lever is the COUNT of non-MFMA vector instructions.  The transform is therefore
-    // specialised per Winograd row (ROW is wave-uniform: waves 2r, 2r+1 own row r) so that the +-1 coefficients of
-    // B^T become add/sub operand order instead of multiplies.
+    // One chunk of work for a wave: 32 MFMAs on V[buf] x u, with the B^T d B transform of chunk `nchunk` into V[buf^1]
+    // threaded between them (sched_group_barrier pins the interleave).  Measured on gfx950 (tests/microbench): the fp32
+    // MFMA does not co-execute with other vector work the way the bf16 matrix core does -- every LDS read, VALU op and
+    // above all every global load a SIMD issues adds its issue time to the MFMA stream, whichever of the two resident
+    // waves issues it -- so the lever is the COUNT of non-MFMA instructions per MFMA.  The transform is therefore
+    // specialised per Winograd row (ROW is wave-uniform: waves 2r, 2r+1 own row r) so that the +-1 coefficients of B^T
+    // are operand order, not multiplies, and the weight operand comes straight from L2 into registers.
     auto chunk_body = [&](int buf, const f32x4 *u, int nchunk, auto row_tag) {
         constexpr int ROW = decltype(row_tag)::value;
         const char *vb = Vb + buf * VBUF_BYTES + h * (TILES * 16) + l31 * 16 + (wp * 4) * (2 * TILES * 16);
@@ -205,10 +202,6 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
 
     if (stamps) st1 = __builtin_amdgcn_s_memrealtime();
     // ---- main loop, two 8-channel chunks per trip (U register sets alternate) ------------------------------
-    // An MFMA-issuing wave blocks its own later instructions (in-order issue), and two SIMD partners that run the
-    // same program in step queue on the matrix pipe together and then leave it idle together.  Waves w and w+4
-    // share a SIMD: waves 0-3 run [MFMA(c), transform(c+1)], waves 4-7 run [transform(c+1), MFMA(c)] -- both
-    // orders are legal inside a chunk -- so one partner's matrix work covers the other's vector/LDS work.
     auto run_chunk = [&](int buf, const f32x4 *u, int nchunk) {
         switch (tr_i) {                               // wave-uniform
         case 0: chunk_body(buf, u, nchunk, std::integral_constant<int, 0>{}); break;
