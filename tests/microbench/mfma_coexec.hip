@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void kmix(float *out, const float *g, int i
     f32x16 acc[8];
     for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     float a = tid * 0.001f, b = 1.0f + lane * 0.01f;
-    f32x4 v = {a, b, a, b}, t = {0, 0, 0, 0}, u[4] = {v, v, v, v}, xs[3] = {v, v, v};
+    f32x4 v = {a, b, a, b}, t = {0, 0, 0, 0}, u[4] = {v, v, v, v}, xs[3] = {v, v, v}, un[4] = {v, v, v, v};
     const char *lp = lds + lane * 16 + wave * 1024;
     const char *lc = lds + 65536 + (lane & 31) * 256 + (lane >> 5) * 16 + wave * 32;   // 256-B stride: 16 lanes of a b128 group on 1 bank quad... 4+ way
     char *lw = lds + 131072 - 8192 + lane * 16 + wave * 1024;
@@ -71,9 +71,11 @@ __global__ __launch_bounds__(512, 2) void kmix(float *out, const float *g, int i
             if ((MIX & 8) && (i & 7) == 2) u[i >> 3] = *(const f32x4 *)(gp + ((it * 4 + (i >> 3)) & 63) * 1024);
             if ((MIX & 64) && (i & 7) == 5 && i < 24) xs[i >> 3] = *(const f32x4 *)(gp + 65536 + ((it * 4 + (i >> 3)) & 63) * 1024);
             if ((MIX & 64) && (i & 7) == 7 && i < 24) *(f32x4 *)(lw - 16384 + (i >> 3) * 1024) = xs[i >> 3];
+            if ((MIX & 128) && (i & 1) && i < 8) un[i >> 1] = *(const f32x4 *)(gp + ((it * 4 + (i >> 1)) & 63) * 1024);
             if (MIX & 16) v.x = v.x * b + a;
         }
         if (MIX & 32) __syncthreads();
+        if (MIX & 128) { u[0] = un[0]; u[1] = un[1]; u[2] = un[2]; u[3] = un[3]; }
     }
     float s = v.x + v.y + v.z + v.w + t.x + t.y + t.z + t.w + u[0].x + u[1].y + u[2].z + u[3].w + xs[0].x + xs[1].x + xs[2].x;
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][7];
@@ -113,6 +115,59 @@ __global__ __launch_bounds__(512, 2) void kmix16(float *out, const float *g, int
     float s = v.x + v.y + v.z + v.w + t.x + t.y + t.z + t.w + u[0].x + u[1].y + u[2].z + u[3].w + xs[0].x + xs[1].x + xs[2].x;
     for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][3];
     if (s == 1234.5f) out[tid] = s;
+}
+
+
+// One wave per SIMD: 4 waves per workgroup, 16 accumulator tiles (256 registers, AGPRs) per wave, 64 MFMAs per iteration --
+// the same MFMA work per SIMD and iteration as kmix with both partner waves, every other instruction issued by the
+// MFMA wave itself.  MIX bits as kmix but scaled to keep the per-SIMD totals: 1 = 8 conflict-free ds_read_b128 (A
+// fragments: one wave reads them for both N halves), 2 = 16 conflicted ds_read_b128, 4 = 8 ds_write_b128,
+// 8 = 8 global_load_dwordx4, 16 = 64 VALU, 32 = barrier, 64 = 6 global loads + 6 ds_write (staging)
+template <int MIX>
+__global__ __launch_bounds__(256) void kmix1(float *out, const float *g, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    f32x16 acc[16];
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = tid * 0.001f, b = 1.0f + lane * 0.01f;
+    f32x4 v = {a, b, a, b}, t = {0, 0, 0, 0}, u[8] = {v, v, v, v, v, v, v, v}, xs[6] = {v, v, v, v, v, v};
+    const char *lp = lds + lane * 16 + wave * 1024;
+    const char *lc = lds + 65536 + (lane & 31) * 256 + (lane >> 5) * 16 + wave * 32;
+    char *lw = lds + 131072 - 8192 + lane * 16 + wave * 1024;
+    const float *gp = g + (size_t)blockIdx.x % 8 * 262144 + wave * 8192 + lane * 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            acc[i & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[i & 7].x + a, b, acc[i & 15], 0, 0, 0);
+            if ((MIX & 1) && (i & 7) == 0) t += *(const f32x4 *)(lp + (i >> 3) * 8192);
+            if ((MIX & 2) && (i & 3) == 1) t += *(const f32x4 *)(lc + (i >> 2) * 4096 % 32768);
+            if ((MIX & 4) && (i & 7) == 6) *(f32x4 *)(lw + (i >> 3) * 65536 % 8192) = t;
+            if ((MIX & 8) && (i & 7) == 2) u[i >> 3] = *(const f32x4 *)(gp + ((it * 8 + (i >> 3)) & 63) * 1024);
+            if ((MIX & 64) && (i & 7) == 5 && i < 48) xs[i >> 3] = *(const f32x4 *)(gp + 65536 + ((it * 8 + (i >> 3)) & 63) * 1024);
+            if ((MIX & 64) && (i & 7) == 7 && i < 48) *(f32x4 *)(lw - 16384 + (i >> 3) * 1024) = xs[i >> 3];
+            if (MIX & 16) v.x = v.x * b + a;
+        }
+        if (MIX & 32) __syncthreads();
+    }
+    float s = v.x + v.y + v.z + v.w + t.x + t.y + t.z + t.w;
+    for (int i = 0; i < 8; ++i) s += u[i].x;
+    for (int i = 0; i < 6; ++i) s += xs[i].x;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][7];
+    if (s == 1234.5f) out[tid] = s;
+}
+
+template <int MIX>
+void runmix1(const char *name, float *d, const float *g) {
+    hipFuncSetAttribute((const void *)kmix1<MIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
+    const int iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kmix1<MIX><<<256, 256, 159744>>>(d, g, 10);
+    hipEventRecord(e0);
+    kmix1<MIX><<<256, 256, 159744>>>(d, g, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double tf = (double)256 * 4 * iters * 64 * 4096 / (ms * 1e-3) / 1e12;
+    printf("1 wave/SIMD mix %3d %-46s %8.3f ms  %6.1f TFLOP/s  cycles/iter/SIMD@2.4GHz %.0f\n", MIX, name, ms, tf, ms * 1e-3 * 2.4e9 / iters);
 }
 
 template <int MIX>
@@ -191,5 +246,20 @@ int main() {
     runmix16<1 + 2 + 4 + 16>("LDS+VALU mix, no barrier", d, g);
     runmix16<1 + 4 + 8 + 16 + 32>("kernel-like mix: 8 reads, 4 writes, 4 loads, 32 VALU, barrier", d, g);
     runmix<1 + 4 + 8 + 16 + 32>("(32x32x2) kernel-like mix: same", d, g);
+    runmix<128>("+4 global loads consumed an iteration later", d, g);
+    runmix<128 + 32>("+4 latency-hidden global loads + barrier", d, g);
+    runmix<128 + 1 + 4 + 16>("hidden loads + 8 reads + 4 writes + 32 VALU", d, g);
+    runmix<128 + 1 + 4 + 16 + 32>("hidden loads + 8 reads + 4 writes + 32 VALU + barrier", d, g);
+    runmix<1 + 4 + 16 + 32>("8 reads + 4 writes + 32 VALU + barrier", d, g);
+    runmix1<0>("MFMA only", d, g);
+    runmix1<1>("+8 ds_read_b128", d, g);
+    runmix1<2>("+16 ds_read_b128 (bank-conflicted)", d, g);
+    runmix1<4>("+8 ds_write_b128", d, g);
+    runmix1<8>("+8 global_load_dwordx4", d, g);
+    runmix1<16>("+64 VALU", d, g);
+    runmix1<32>("+barrier", d, g);
+    runmix1<1 + 2 + 4 + 16>("LDS+VALU mix, no barrier", d, g);
+    runmix1<1 + 2 + 4 + 8 + 16 + 32>("full chunk mix (no staging)", d, g);
+    runmix1<1 + 2 + 4 + 8 + 16 + 32 + 64>("full chunk mix + staging", d, g);
     return 0;
 }

@@ -21,6 +21,7 @@
 // Epilogue: the column half of A^T M A in registers, the row half across the 4 waves of a channel half through
 // LDS (the 128 KB of chunk buffers are reused), then bias + residual + ReLU and coalesced NHWC stores.
 // Blocks are dealt so that each XCD works on one 64-channel slice of U at a time (1 MB at C=256: L2-resident).
+#include <cstdlib>
 #include <type_traits>
 
 #include "xq_common.h"
@@ -286,6 +287,258 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Second decomposition: workgroup = 32 tiles x 64 output channels, 4 waves, two workgroups resident per CU.
+// Wave p owns Winograd row p (xi = 4p..4p+3) for all 64 channels: 4 xi x 1 M-tile x 2 N-tiles = 8 accumulator tiles.
+// Lane (h, m) of wave p needs, as its MFMA A operand, V[xi][tile m][ci = 4h..4h+3] -- exactly the four values the
+// transform of (tile m, channel quad h, row p) produces, so every lane transforms what it multiplies: no V buffers in
+// LDS, no A-fragment reads, and only the raw-input staging needs a barrier (one per 16 channels).  The two workgroups
+// of a CU run unsynchronised, so one's prologue, barrier waits and epilogue are covered by the other's MFMAs.
+//
+// Staged input: boards with a zero halo, position P(b, y, x) = (11 b + y + 1) * 10 + x + 1 for y in [-1, 10], x in
+// [-1, 9] (row 10 of a board is row -1 of the next, column 9 of a row is column -1 of the next: all zero and never
+// written), 80 bytes per position (16 channels + 16 B pad).  A tile's 4x4 patch is then base + (10 r + c) * 80: one
+// address register and immediates, no bounds logic.
+constexpr int T2 = 32;                       // tiles per workgroup
+constexpr int XPOS2 = (3 * 11 + 1) * 10 + 1; // 3 boards with halo: 341 positions
+constexpr int XRAW2 = XPOS2 * XSTRIDE;       // 27280 B per staging buffer
+constexpr int E2_BYTES = 4 * 2 * T2 * NCO * 4;          // epilogue exchange [row p][b][tile][co] (64 KB)
+constexpr int LDS2_BYTES = 2 * XRAW2 > E2_BYTES ? 2 * XRAW2 : E2_BYTES;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__global__ __launch_bounds__(256, 2) void k_wino_conv2(const float *__restrict__ X, const float *__restrict__ Ug,
+                                                       const float *__restrict__ bias, const float *__restrict__ R,
+                                                       float *__restrict__ Y, int B, int C, int relu, int n_groups) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *Xr = lds;                                   // [2][341][80 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wp = tid >> 6;
+    const int NG = C / NCO;                           // channel groups; divides 8
+    const int per = 8 / NG;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int cog = xcd % NG;
+    const int tg = rr * per + xcd / NG;
+    if (tg >= n_groups) return;
+    const int T = B * 25;
+    const int t0 = tg * T2;
+    const int b_lo = t0 / 25;
+    const int NCH = C / KC;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // ---- transform / MFMA role: tile l31, channel quad h, Winograd row wp --------------------------------
+    const int gt = t0 + l31 < T ? t0 + l31 : T - 1;   // tiles past the end recompute the last one (never stored)
+    const int tb = gt / 25, tt = gt - tb * 25, ty = tt / 5, tx = tt - ty * 5;
+    const int tbase = (((tb - b_lo) * 11 + 2 * ty) * 10 + 2 * tx) * XSTRIDE + h * 16;   // P(tb, 2ty-1, 2tx-1)
+
+    // ---- staging role: only the rows some tile of this group reads are fetched (from the first tile's halo in the first
+    // board to the last tile's in the last): a contiguous run of at most 162 positions = 648 float4 per 16-channel
+    // superchunk, 3 slots per thread
+    const int tl = (t0 + T2 - 1 < T ? t0 + T2 - 1 : T - 1);
+    const int b_hi = tl / 25;
+    const int y_min = 2 * ((t0 - b_lo * 25) / 5) - 1, y_max = 2 * ((tl - b_hi * 25) / 5) + 2;
+    const int pos_first = (y_min > 0 ? y_min : 0) * 9;
+    const int pos_last = (b_hi - b_lo) * 90 + ((y_max < 9 ? y_max : 9) + 1) * 9 - 1;
+    const int spos = pos_first + (tid >> 2), spart = tid & 3;
+    const unsigned xgo = (unsigned)(((long long)b_lo * 90 + spos) * C + spart * 4) * 4u;      // byte offset of slot 0
+    const unsigned xstep = 64u * (unsigned)C * 4u;                                            // 64 positions further
+    bool xv[3];
+    int xl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pos = spos + 64 * k;
+        const int bi = pos / 90, rem = pos - bi * 90, y = rem / 9, x = rem - y * 9;
+        xv[k] = pos <= pos_last;
+        xl[k] = ((bi * 11 + y + 1) * 10 + x + 1) * XSTRIDE + spart * 16;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((unsigned)B * 90u * (unsigned)C * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)(Ug + (size_t)cog * NCH * (UBUF_BYTES / 4)), 0,
+                                                                         NCH * UBUF_BYTES, 0x00020000);
+    // B operand: lane (h, n) needs U[xi][8*chunk + 4h + j][64*cog + 32*nt + n], j = 0..3
+    const unsigned ul = (h * (NCO * 4) + l31 * 4 + (wp * 4) * (2 * NCO * 4)) * 4;   // byte offset in a chunk
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][n][e] = 0.0f;
+
+    f32x4 xreg[3];
+    auto load_x = [&](int super) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            xreg[k] = xv[k] ? buf_ld4(xrs, xgo, super * 64 + k * xstep) : z;
+        }
+    };
+    auto store_x = [&](int super) __attribute__((always_inline)) {
+        char *dst = Xr + (super & 1) * XRAW2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (xv[k]) *(f32x4 *)(dst + xl[k]) = xreg[k];
+    };
+    f32x4 a[4], u[4][2];
+    // prologue transform of chunk 0: rows r1, r2 of B^T d for each column, then the column transform
+    auto transform0 = [&](auto row_tag) __attribute__((always_inline)) {
+        constexpr int ROW = decltype(row_tag)::value;
+        constexpr int R1 = ROW == 0 ? 0 : 1, R2 = ROW == 3 ? 3 : 2;
+        f32x4 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 d1 = ld4(Xr + tbase + (R1 * 10 + q) * XSTRIDE), d2 = ld4(Xr + tbase + (R2 * 10 + q) * XSTRIDE);
+            w[q] = ROW == 2 ? d2 - d1 : ROW == 1 ? d1 + d2 : d1 - d2;
+        }
+        a[0] = w[0] - w[2]; a[1] = w[1] + w[2]; a[2] = w[2] - w[1]; a[3] = w[1] - w[3];
+    };
+    auto load_u = [&](int chunk, int q) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)chunk * UBUF_BYTES + q * (2 * NCO * 16);      // wave-uniform
+        u[q][0] = buf_ld4(urs, ul, so);
+        u[q][1] = buf_ld4(urs, ul, so + 32 * 16);
+    };
+#define XQ_PIN(v) asm volatile("" : "+v"(v))
+    // One chunk: 32 MFMAs on (a, u); the transform of the NEXT chunk (raw data at LDS offset XO, a compile-time
+    // constant: staging buffer and chunk parity) and its weights replace a and u as they retire.  The instruction order
+    // is pinned by hand (a sched_barrier fence every two MFMAs, empty asm pins on the VALU results): the raw columns are
+    // read in the order 0, 2, 1, 3 so that the next chunk's first A fragment (w0 - w2) is ready early, each column's two
+    // LDS reads sit two MFMA pairs ahead of the VALU that consumes them, at most four VALU share a fence with an
+    // MFMA pair, and the two weight loads of a frequency are issued right behind its last MFMA -- a whole chunk ahead
+    // of their use.
+    auto chunk_body = [&](int uchunk, auto row_tag, auto xo_tag) __attribute__((always_inline)) {
+        constexpr int ROW = decltype(row_tag)::value;
+        constexpr int XO = decltype(xo_tag)::value;
+        constexpr int R1 = ROW == 0 ? 0 : 1, R2 = ROW == 3 ? 3 : 2;
+        const char *xr = Xr + tbase + XO;
+        f32x4 w[4], d1, d2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj == 0) { d1 = ld4(xr + (R1 * 10 + col) * XSTRIDE); d2 = ld4(xr + (R2 * 10 + col) * XSTRIDE); }
+                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], u[q][0][jj], acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], u[q][1][jj], acc[q][1], 0, 0, 0);
+                if (jj == 0 && q == 3) { a[2] = w[2] - w[1]; XQ_PIN(a[2]); }
+                if (jj == 2) {
+                    w[col] = ROW == 2 ? d2 - d1 : ROW == 1 ? d1 + d2 : d1 - d2;
+                    XQ_PIN(w[col]);
+                }
+                if (jj == 3) {
+                    load_u(uchunk, q);
+                    if (q == 1) { a[0] = w[0] - w[2]; XQ_PIN(a[0]); }
+                    if (q == 2) { a[1] = w[1] + w[2]; XQ_PIN(a[1]); }
+                    if (q == 3) { a[3] = w[1] - w[3]; XQ_PIN(a[3]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto run_chunk = [&](int uchunk, auto xo_tag) __attribute__((always_inline)) {
+        switch (wp) {                                 // wave-uniform
+        case 0: chunk_body(uchunk, std::integral_constant<int, 0>{}, xo_tag); break;
+        case 1: chunk_body(uchunk, std::integral_constant<int, 1>{}, xo_tag); break;
+        case 2: chunk_body(uchunk, std::integral_constant<int, 2>{}, xo_tag); break;
+        default: chunk_body(uchunk, std::integral_constant<int, 3>{}, xo_tag); break;
+        }
+    };
+
+    // ---- prologue ------------------------------------------------------------------------------------------
+    const int NSUP = NCH / 2;
+    load_x(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_u(0, q);
+    {                                                 // zero both staging buffers (the halo stays zero from here on)
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int o = tid * 16; o < 2 * XRAW2; o += 256 * 16) *(f32x4 *)(Xr + o) = z;
+    }
+    __syncthreads();
+    store_x(0);
+    __syncthreads();
+    if (NSUP > 1) load_x(1);
+    switch (wp) {
+    case 0: transform0(std::integral_constant<int, 0>{}); break;
+    case 1: transform0(std::integral_constant<int, 1>{}); break;
+    case 2: transform0(std::integral_constant<int, 2>{}); break;
+    default: transform0(std::integral_constant<int, 3>{}); break;
+    }
+
+    // ---- main loop: two 16-channel superchunks (four chunks) per trip, one barrier per superchunk ----------------
+    // Chunk c multiplies with (a, u) of chunk c while transforming chunk c+1; superchunk s is staged in buffer s & 1.
+    for (int c = 0; c < NCH; c += 4) {
+        const int sup = c >> 1;                       // even
+        // chunk c: superchunk sup+1 goes to buffer 1 (last read during chunk c-2, before the previous barrier)
+        if (sup + 1 < NSUP) {
+            store_x(sup + 1);
+            if (sup + 2 < NSUP) load_x(sup + 2);
+        }
+        run_chunk(c + 1, std::integral_constant<int, 32>{});                        // chunk c+1: buffer 0, upper half
+        __syncthreads();
+        run_chunk(c + 2, std::integral_constant<int, XRAW2>{});                     // chunk c+2: buffer 1, lower half
+        if (sup + 2 < NSUP) {
+            store_x(sup + 2);
+            if (sup + 3 < NSUP) load_x(sup + 3);
+        }
+        run_chunk(c + 3, std::integral_constant<int, XRAW2 + 32>{});                // chunk c+3: buffer 1, upper half
+        __syncthreads();
+        // the last trip transforms stale data for a chunk that does not exist; its weights are re-read from chunk c+3
+        run_chunk(c + 4 < NCH ? c + 4 : c + 3, std::integral_constant<int, 0>{});   // chunk c+4: buffer 0, lower half
+    }
+#undef XQ_PIN
+    __syncthreads();                                  // staging buffers become the exchange planes
+
+    // ---- epilogue: Y = A^T M A, bias, residual, ReLU --------------------------------------------------------
+    const int c4 = tid & 15;
+    const int co = c4 * 4;
+    const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + co);
+    size_t oaddr[8];
+    f32x4 resv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int pidx = it * 16 + (tid >> 4);
+        const int tile = pidx >> 2, ya = (pidx >> 1) & 1, yb = pidx & 1;
+        const int g = t0 + tile;
+        const int bd = g / 25, t2 = g - bd * 25, ty2 = t2 / 5, tx2 = t2 - ty2 * 5;
+        const int oy = 2 * ty2 + ya, ox = 2 * tx2 + yb;
+        const bool ok = g < T && ox < 9;
+        oaddr[it] = ok ? ((size_t)bd * 90 + oy * 9 + ox) * C + cog * NCO + co : (size_t)-1;
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        resv[it] = (ok && R) ? *(const f32x4 *)(R + oaddr[it]) : z;
+    }
+    // column half in registers: b=0: M0+M1+M2, b=1: M1-M2-M3 (A^T = [[1,1,1,0],[0,1,-1,-1]])
+    float *E = (float *)lds;                          // [4 rows p][2 b][32 tiles][64 co]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const f32x16 y0 = acc[0][n] + acc[1][n] + acc[2][n];
+        const f32x16 y1 = acc[1][n] - acc[2][n] - acc[3][n];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tile = (e & 3) + 8 * (e >> 2) + 4 * h;
+            E[((wp * 2 + 0) * T2 + tile) * NCO + 32 * n + l31] = y0[e];
+            E[((wp * 2 + 1) * T2 + tile) * NCO + 32 * n + l31] = y1[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int pidx = it * 16 + (tid >> 4);
+        const int tile = pidx >> 2, ya = (pidx >> 1) & 1, yb = pidx & 1;
+        if (oaddr[it] == (size_t)-1) continue;
+        const float *e0 = E + (yb * T2 + tile) * NCO + co;
+        const int pstride = 2 * T2 * NCO;             // next Winograd row p
+        f32x4 y;
+        if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
+        else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
+        y = y + bv + resv[it];
+        if (relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
+        *(f32x4 *)(Y + oaddr[it]) = y;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,6 +556,21 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     if (!attr_set) {
         XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
+    }
+    static const bool v1 = getenv("XQ_WINO_V1") != nullptr;
+    if (!v1) {
+        if ((unsigned long long)batch * 90ull * (unsigned)channels * 4ull >= (1ull << 32)) return XQ_ERR_ARG;   // 32-bit staging offsets
+        static thread_local bool attr2_set = false;
+        if (!attr2_set) {
+            XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES));
+            attr2_set = true;
+        }
+        const int n_groups = (batch * 25 + T2 - 1) / T2;
+        const int per = 8 / (channels / NCO);
+        const int rows = (n_groups + per - 1) / per;
+        hipLaunchKernelGGL(k_wino_conv2, dim3(rows * 8), dim3(256), LDS2_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+                           dev_residual, dev_y, batch, channels, relu, n_groups);
+        return xq::launch_status();
     }
     const int n_groups = (batch * 25 + TILES - 1) / TILES;
     const int ng = channels / NCO;
