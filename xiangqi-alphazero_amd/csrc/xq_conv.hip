@@ -302,10 +302,26 @@ __global__ __launch_bounds__(512, 2) void k_wino_conv(const float *__restrict__ 
 // address register and immediates, no bounds logic.
 constexpr int T2 = 32;                       // tiles per workgroup
 constexpr int XPOS2 = (3 * 11 + 1) * 10 + 1; // 3 boards with halo: 341 positions
-constexpr int XRAW2 = XPOS2 * XSTRIDE;       // 27280 B per staging buffer
+constexpr int XRAW2 = (XPOS2 + 1) * XSTRIDE; // 27360 B per staging buffer (+ one dump position)
 constexpr int E2_BYTES = 4 * 2 * T2 * NCO * 4;          // epilogue exchange [row p][b][tile][co] (64 KB)
 constexpr int LDS2_BYTES = 2 * XRAW2 > E2_BYTES ? 2 * XRAW2 : E2_BYTES;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// a - b / a + b on four floats as two packed instructions (v_pk_add_f32 has per-operand negation; the compiler only
+// emits the packed form for additions).  Exactly the IEEE results of the scalar forms.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(f32x2{a.x, a.y}), "v"(f32x2{b.x, b.y}));
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f32x2{a.z, a.w}), "v"(f32x2{b.z, b.w}));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a.x, a.y}), "v"(f32x2{b.x, b.y}));
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a.z, a.w}), "v"(f32x2{b.z, b.w}));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
@@ -334,6 +350,12 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(const float *__restrict__
     const int gt = t0 + l31 < T ? t0 + l31 : T - 1;   // tiles past the end recompute the last one (never stored)
     const int tb = gt / 25, tt = gt - tb * 25, ty = tt / 5, tx = tt - ty * 5;
     const int tbase = (((tb - b_lo) * 11 + 2 * ty) * 10 + 2 * tx) * XSTRIDE + h * 16;   // P(tb, 2ty-1, 2tx-1)
+    // Row p of B^T d is d[r1] + s d[r2] with (r1, r2, s) = (0,2,-), (1,2,+), (1,2,-), (1,3,-); row 2 is therefore the
+    // NEGATIVE of the textbook d2 - d1, and the pre-transformed weights of its four frequencies carry the other minus
+    // sign (include/xq_hip.h).  One code path serves all four waves: the row is data (two base addresses and a sign).
+    const int tb1 = tbase + (wp == 0 ? 0 : 10) * XSTRIDE, tb2 = tbase + (wp == 3 ? 30 : 20) * XSTRIDE;
+    const float sg = wp == 1 ? 1.0f : -1.0f;
+    const f32x2 sgn = {sg, sg};
 
     // ---- staging role: only the rows some tile of this group reads are fetched (from the first tile's halo in the first
     // board to the last tile's in the last): a contiguous run of at most 162 positions = 648 float4 per 16-channel
@@ -346,14 +368,17 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(const float *__restrict__
     const int spos = pos_first + (tid >> 2), spart = tid & 3;
     const unsigned xgo = (unsigned)(((long long)b_lo * 90 + spos) * C + spart * 4) * 4u;      // byte offset of slot 0
     const unsigned xstep = 64u * (unsigned)C * 4u;                                            // 64 positions further
-    bool xv[3];
+    // Slots past the run load nothing (offset beyond the buffer's range: the load returns zeros without a fetch) and
+    // store into a dump position behind the staged image, so the staging code has no divergent control flow.
+    unsigned xgk[3];
     int xl[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int pos = spos + 64 * k;
         const int bi = pos / 90, rem = pos - bi * 90, y = rem / 9, x = rem - y * 9;
-        xv[k] = pos <= pos_last;
-        xl[k] = ((bi * 11 + y + 1) * 10 + x + 1) * XSTRIDE + spart * 16;
+        const bool ok = pos <= pos_last;
+        xgk[k] = ok ? xgo + k * xstep : 0xFFFFFFF0u;
+        xl[k] = (ok ? (bi * 11 + y + 1) * 10 + x + 1 : XPOS2) * XSTRIDE + spart * 16;
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((unsigned)B * 90u * (unsigned)C * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)(Ug + (size_t)cog * NCH * (UBUF_BYTES / 4)), 0,
@@ -372,28 +397,25 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(const float *__restrict__
     f32x4 xreg[3];
     auto load_x = [&](int super) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            xreg[k] = xv[k] ? buf_ld4(xrs, xgo, super * 64 + k * xstep) : z;
-        }
+        for (int k = 0; k < 3; ++k) xreg[k] = buf_ld4(xrs, xgk[k], super * 64);
     };
     auto store_x = [&](int super) __attribute__((always_inline)) {
         char *dst = Xr + (super & 1) * XRAW2;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (xv[k]) *(f32x4 *)(dst + xl[k]) = xreg[k];
+        for (int k = 0; k < 3; ++k) *(f32x4 *)(dst + xl[k]) = xreg[k];
     };
     f32x4 a[4], u[4][2];
+    auto rowpair = [&](f32x4 d1, f32x4 d2) __attribute__((always_inline)) {      // d1 + sgn * d2, two packed FMAs
+        f32x2 lo, hi;                                 // fma(d2, +-1, d1) rounds once: exactly d1 +- d2
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(f32x2{d2.x, d2.y}), "v"(sgn), "v"(f32x2{d1.x, d1.y}));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(f32x2{d2.z, d2.w}), "v"(sgn), "v"(f32x2{d1.z, d1.w}));
+        return f32x4{lo.x, lo.y, hi.x, hi.y};
+    };
     // prologue transform of chunk 0: rows r1, r2 of B^T d for each column, then the column transform
-    auto transform0 = [&](auto row_tag) __attribute__((always_inline)) {
-        constexpr int ROW = decltype(row_tag)::value;
-        constexpr int R1 = ROW == 0 ? 0 : 1, R2 = ROW == 3 ? 3 : 2;
+    auto transform0 = [&]() __attribute__((always_inline)) {
         f32x4 w[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 d1 = ld4(Xr + tbase + (R1 * 10 + q) * XSTRIDE), d2 = ld4(Xr + tbase + (R2 * 10 + q) * XSTRIDE);
-            w[q] = ROW == 2 ? d2 - d1 : ROW == 1 ? d1 + d2 : d1 - d2;
-        }
+        for (int q = 0; q < 4; ++q) w[q] = rowpair(ld4(Xr + tb1 + q * XSTRIDE), ld4(Xr + tb2 + q * XSTRIDE));
         a[0] = w[0] - w[2]; a[1] = w[1] + w[2]; a[2] = w[2] - w[1]; a[3] = w[1] - w[3];
     };
     auto load_u = [&](int chunk, int q) __attribute__((always_inline)) {
@@ -409,41 +431,28 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(const float *__restrict__
     // LDS reads sit two MFMA pairs ahead of the VALU that consumes them, at most four VALU share a fence with an
     // MFMA pair, and the two weight loads of a frequency are issued right behind its last MFMA -- a whole chunk ahead
     // of their use.
-    auto chunk_body = [&](int uchunk, auto row_tag, auto xo_tag) __attribute__((always_inline)) {
-        constexpr int ROW = decltype(row_tag)::value;
+    auto chunk_body = [&](int uchunk, auto xo_tag, int stage) __attribute__((always_inline)) {
         constexpr int XO = decltype(xo_tag)::value;
-        constexpr int R1 = ROW == 0 ? 0 : 1, R2 = ROW == 3 ? 3 : 2;
-        const char *xr = Xr + tbase + XO;
         f32x4 w[4], d1, d2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                if (jj == 0) { d1 = ld4(xr + (R1 * 10 + col) * XSTRIDE); d2 = ld4(xr + (R2 * 10 + col) * XSTRIDE); }
+                if (jj == 0) { d1 = ld4(Xr + tb1 + XO + col * XSTRIDE); d2 = ld4(Xr + tb2 + XO + col * XSTRIDE); }
                 acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], u[q][0][jj], acc[q][0], 0, 0, 0);
                 acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], u[q][1][jj], acc[q][1], 0, 0, 0);
-                if (jj == 0 && q == 3) { a[2] = w[2] - w[1]; XQ_PIN(a[2]); }
-                if (jj == 2) {
-                    w[col] = ROW == 2 ? d2 - d1 : ROW == 1 ? d1 + d2 : d1 - d2;
-                    XQ_PIN(w[col]);
-                }
+                if (jj == 0 && q == 3) a[2] = pk_sub4(w[2], w[1]);
+                if (jj == 2) w[col] = rowpair(d1, d2);
+                if (jj == 1 && q == 3 && stage >= 0) { store_x(stage); load_x(stage + 1); }
                 if (jj == 3) {
                     load_u(uchunk, q);
-                    if (q == 1) { a[0] = w[0] - w[2]; XQ_PIN(a[0]); }
-                    if (q == 2) { a[1] = w[1] + w[2]; XQ_PIN(a[1]); }
-                    if (q == 3) { a[3] = w[1] - w[3]; XQ_PIN(a[3]); }
+                    if (q == 1) a[0] = pk_sub4(w[0], w[2]);
+                    if (q == 2) a[1] = pk_add4(w[1], w[2]);
+                    if (q == 3) a[3] = pk_sub4(w[1], w[3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-    };
-    auto run_chunk = [&](int uchunk, auto xo_tag) __attribute__((always_inline)) {
-        switch (wp) {                                 // wave-uniform
-        case 0: chunk_body(uchunk, std::integral_constant<int, 0>{}, xo_tag); break;
-        case 1: chunk_body(uchunk, std::integral_constant<int, 1>{}, xo_tag); break;
-        case 2: chunk_body(uchunk, std::integral_constant<int, 2>{}, xo_tag); break;
-        default: chunk_body(uchunk, std::integral_constant<int, 3>{}, xo_tag); break;
         }
     };
 
@@ -459,34 +468,25 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(const float *__restrict__
     __syncthreads();
     store_x(0);
     __syncthreads();
-    if (NSUP > 1) load_x(1);
-    switch (wp) {
-    case 0: transform0(std::integral_constant<int, 0>{}); break;
-    case 1: transform0(std::integral_constant<int, 1>{}); break;
-    case 2: transform0(std::integral_constant<int, 2>{}); break;
-    default: transform0(std::integral_constant<int, 3>{}); break;
-    }
+    load_x(1);
+    transform0();
 
     // ---- main loop: two 16-channel superchunks (four chunks) per trip, one barrier per superchunk ----------------
     // Chunk c multiplies with (a, u) of chunk c while transforming chunk c+1; superchunk s is staged in buffer s & 1.
     for (int c = 0; c < NCH; c += 4) {
         const int sup = c >> 1;                       // even
-        // chunk c: superchunk sup+1 goes to buffer 1 (last read during chunk c-2, before the previous barrier)
-        if (sup + 1 < NSUP) {
-            store_x(sup + 1);
-            if (sup + 2 < NSUP) load_x(sup + 2);
-        }
-        run_chunk(c + 1, std::integral_constant<int, 32>{});                        // chunk c+1: buffer 0, upper half
+        // chunk c stores superchunk sup+1 into buffer 1 (last read during chunk c-2, before the previous barrier) and
+        // fetches sup+2 into the staging registers; chunk c+2 does the same one further.  Both sit late in their chunk,
+        // behind the waits for that chunk's weights, so the in-order load counter does not make the store wait for
+        // younger weight loads.  Past the last superchunk the stores put stale registers into a free buffer and the
+        // loads fetch channels of the next positions or zeros: never used.
+        chunk_body(c + 1, std::integral_constant<int, 32>{}, sup + 1);              // transforms chunk c+1: buffer 0, upper half
         __syncthreads();
-        run_chunk(c + 2, std::integral_constant<int, XRAW2>{});                     // chunk c+2: buffer 1, lower half
-        if (sup + 2 < NSUP) {
-            store_x(sup + 2);
-            if (sup + 3 < NSUP) load_x(sup + 3);
-        }
-        run_chunk(c + 3, std::integral_constant<int, XRAW2 + 32>{});                // chunk c+3: buffer 1, upper half
+        chunk_body(c + 2, std::integral_constant<int, XRAW2>{}, -1);                // chunk c+2: buffer 1, lower half
+        chunk_body(c + 3, std::integral_constant<int, XRAW2 + 32>{}, sup + 2);      // chunk c+3: buffer 1, upper half
         __syncthreads();
         // the last trip transforms stale data for a chunk that does not exist; its weights are re-read from chunk c+3
-        run_chunk(c + 4 < NCH ? c + 4 : c + 3, std::integral_constant<int, 0>{});   // chunk c+4: buffer 0, lower half
+        chunk_body(c + 4 < NCH ? c + 4 : c + 3, std::integral_constant<int, 0>{}, -1);   // chunk c+4: buffer 0, lower half
     }
 #undef XQ_PIN
     __syncthreads();                                  // staging buffers become the exchange planes

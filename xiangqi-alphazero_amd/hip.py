@@ -222,6 +222,7 @@ def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:
         raise XqError("wino_transform_weights: [C,C,3,3] with C in {64,128,256,512} required")
     g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
     u = torch.einsum("pr,oirs,qs->pqoi", g, w.detach().to("cpu", torch.float64), g)      # [4,4,co,ci]
+    u[2] = -u[2]                    # the kernel forms row 2 of B^T d as d1 - d2 (the negative of the textbook row)
     u = u.reshape(16, c // 64, 64, c // 8, 2, 4)                                           # xi, cog, co, chunk, quad, j
     u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, j
     return u.to(w.device)
