@@ -200,18 +200,13 @@ int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, 
  * as fused Winograd F(2x2,3x3) on the fp32 MFMA:  y = act(conv(x) + bias (+ residual)).
  *   dev_x, dev_y, dev_residual : float32[batch][90][channels] (NHWC; y must not alias x or residual)
  *   dev_u : pre-transformed weights, float32[C/64][C/8][16][2][64][4] with
- *           u[cog][chunk][4p+q][quad][co][j] = (G g G^T)[p][q] for output channel 64*cog+co and input channel
- *           8*chunk+4*quad+j, g = the folded 3x3 filter (cross-correlation, as torch.nn.Conv2d);
- *           xq_wino_weight_bytes(C) bytes.  channels in {64, 128, 256, 512}. */
+ *           u[cog][chunk][4p+q][quad][co][j] = s_p (G g G^T)[p][q] for output channel 64*cog+co and input channel
+ *           8*chunk+4*quad+j, g = the folded 3x3 filter (cross-correlation, as torch.nn.Conv2d), s_p = -1 for
+ *           p = 2 and +1 otherwise (the kernel forms row 2 of B^T d with the opposite sign);
+ *           xq_wino_weight_bytes(C) bytes.  channels in {64, 128, 256, 512}; batch*90*channels*4 < 2^32. */
 size_t xq_wino_weight_bytes(int channels);
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
                     float *dev_y, int batch, int channels, int relu, void *stream);
-
-/* Diagnostic twin of xq_wino_conv3x3 (perf analysis only, tests/perf_conv_stamps.py): same computation, plus per
- * workgroup 100 MHz timestamps {start, after prologue, after main loop, end, XCC id} and the HW_ID of each of its 8
- * waves into dev_stamps[grid][16] (uint64), grid = 8 * ceil(ceil(batch*25/64) / (8 / (channels/64))). */
-int xq_wino_conv3x3_dbg(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
-                        float *dev_y, int batch, int channels, int relu, unsigned long long *dev_stamps, void *stream);
 
 /* =====================================================================================
  * Next row (section 8f.1) -- training-batch materialisation.  Replaces SelfPlayDataset.__getitem__ + augment_data

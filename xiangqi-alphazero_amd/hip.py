@@ -95,7 +95,6 @@ def lib():
     L.xq_engine_read_root.argtypes = [C.POINTER(Engine), i32, vp, vp, vp, vp, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     L.xq_bias_act.argtypes = [vp, vp, vp, C.c_longlong, i32, i32, vp]
-    L.xq_wino_conv3x3_dbg.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.xq_samples_to_batch.argtypes = [vp, vp, vp, i32, C.c_double, vp, vp, vp, vp]
     L.xq_wino_weight_bytes.argtypes = [i32]
     L.xq_wino_weight_bytes.restype = C.c_size_t
@@ -108,7 +107,7 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_encode_batch", "xq_material_batch", "xq_apply_moves_batch", "xq_game_over_batch",
            "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
            "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
-           "xq_bias_act", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_wino_conv3x3_dbg", "xq_samples_to_batch"]
+           "xq_bias_act", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch"]
 
 
 def check(rc: int, what: str):

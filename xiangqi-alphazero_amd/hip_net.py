@@ -95,7 +95,7 @@ class HipResNetEvaluator:
         ms = [a.elapsed_time(b) for a, b in self._events]
         avg = sum(ms) / len(ms)
         direct = 2.0 * 90 * 9 * self.C * self.C * batch
-        tiles = (batch * 25 + 63) // 64 * 64
+        tiles = (batch * 25 + 31) // 32 * 32
         mfma = 16 * 2.0 * tiles * self.C * self.C
         ach = direct / (avg * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "k_wino_conv (fused Winograd F(2x2,3x3) 3x3 conv, fp32 MFMA 32x32x2)",
