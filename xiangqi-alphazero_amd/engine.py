@@ -118,6 +118,22 @@ class SelfPlayEngine:
                                            len(res), C.byref(nr), hip.stream_ptr(self.device)), "xq_engine_drain")
         return smp[:ns.value].copy(), res[:nr.value].copy()
 
+    def arena_views(self) -> dict:
+        """Zero-copy torch views of the SoA tree arenas in the workspace, [G, node_cap] each:
+        N int32, W float64, P float32, action int16 (uint16 bits), first int32 (first child, -1 = none), meta int16
+        (uint16 bits: child count | kind << 14), plus the root boards int8 [G, 96] (90 squares + pad).  For inspection and tests."""
+        base = int(self.ws.data_ptr())
+        cap = int(self.h.node_cap)
+
+        def view(idx, dtype, cols):
+            off = int(self.h.p[idx]) - base
+            nbytes = self.G * cols * torch.empty(0, dtype=dtype).element_size()
+            return self.ws[off:off + nbytes].view(dtype).view(self.G, cols)
+
+        return dict(N=view(6, torch.int32, cap), W=view(7, torch.float64, cap), P=view(8, torch.float32, cap),
+                    action=view(9, torch.int16, cap), first=view(10, torch.int32, cap), meta=view(11, torch.int16, cap),
+                    board=view(0, torch.int8, 96), node_cap=cap)
+
     # ---- MCTS.search for a given position (manual_moves engines; mcts.py:94-155) ---------------------------
     def set_position(self, slot: int, board, side: int, move_count: int = 0, no_capture: int = 0, hist12=None,
                      noise=None):
