@@ -118,3 +118,23 @@ def test_parallel_self_play_signature_matches_reference():
         num_simulations = 8
     with pytest.raises(AttributeError):
         selfplay.parallel_self_play(None, Cfg())
+
+
+def test_reachable_actions_cover_every_legal_move():
+    """The policy head's pruned column set (hip_net.py) must contain every move the rules can generate: all fixture
+    positions of the reference, and arbitrary piece placements (pieces on squares the rules never put them on)."""
+    from xiangqi_alphazero_amd.sample_format import reachable_actions
+    reach = np.zeros(8100, dtype=bool)
+    reach[reachable_actions()] = True
+    assert reach.sum() == 2550
+    for d in (G.corpus(), G.crafted()):
+        for i in range(len(d["board"])):
+            assert reach[G.moves_of(d, i).astype(np.int64)].all()
+    rs = np.random.RandomState(11)
+    for _ in range(300):
+        b = np.zeros(90, dtype=np.int8)
+        sq = rs.choice(90, 34, replace=False)
+        b[sq[:32]] = rs.choice([1, 2, 3, 4, 5, 6, 7, -1, -2, -3, -4, -5, -6, -7], 32)
+        b[sq[32]], b[sq[33]] = 1, -1                                  # at least one king each
+        for side in (1, -1):
+            assert reach[np.asarray(O.legal_actions(b, side), dtype=np.int64)].all()

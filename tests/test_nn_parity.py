@@ -141,5 +141,20 @@ def test_hip_tower_evaluator_matches_reference(ch, nb):
     net.load_state_dict(weights.make_state_dict(ch, nb))
     ev, name = evaluator.make_evaluator(net, "cuda", "hip")
     assert name.startswith("hip")
-    logits, v = ev(torch.from_numpy(states).cuda())
-    _check(g, "%dx%d" % (ch, nb), torch.softmax(logits, 1).cpu().numpy(), v.cpu().numpy().reshape(-1))
+    x = torch.from_numpy(states).cuda()
+    full, v = ev(x, full_policy=True)                                # all 8100 columns, the `.predict` path
+    full = full.clone()
+    _check(g, "%dx%d" % (ch, nb), torch.softmax(full, 1).cpu().numpy(), v.cpu().numpy().reshape(-1))
+    # engine-facing call: the same logits in the columns a piece can ever move along, -inf in the others, so the
+    # distribution over any set of legal moves is the reference's (softmax, then renormalise over the legal moves)
+    from xiangqi_alphazero_amd.sample_format import reachable_actions
+    reach = torch.from_numpy(reachable_actions()).cuda()
+    logits, v2 = ev(x)
+    assert torch.equal(v, v2)
+    other = torch.ones(8100, dtype=torch.bool, device="cuda")
+    other[reach] = False
+    assert bool(torch.isneginf(logits[:, other]).all())
+    np.testing.assert_allclose(logits[:, reach].cpu().numpy(), full[:, reach].cpu().numpy(), rtol=0, atol=2e-5)
+    want = torch.softmax(full, 1)[:, reach]
+    want = want / want.sum(1, keepdim=True)
+    np.testing.assert_allclose(torch.softmax(logits, 1)[:, reach].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=TOL)

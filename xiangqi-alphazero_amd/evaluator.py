@@ -52,13 +52,13 @@ class BatchedEvaluator:
 
 
 def make_evaluator(net: XiangqiNet, device, kind: str = "auto"):
-    """-> (callable evaluator, name).  'hip': hand-written MFMA conv tower (csrc/xq_conv.hip) when the library
-    exports it; 'torch': PyTorch-ROCm ops (MIOpen/hipBLASLt); 'auto' prefers 'hip'."""
+    """-> (callable evaluator for the engine, name).  'hip': hand-written MFMA conv tower (csrc/xq_conv.hip) when the
+    library exports it, policy logits only in the columns a piece can ever move along (-inf elsewhere, hip_net.py); 'torch': PyTorch-ROCm ops (MIOpen/hipBLASLt); 'auto' prefers 'hip'."""
     from . import hip
     if kind in ("auto", "hip"):
         try:
             from .hip_net import HipResNetEvaluator
-            return HipResNetEvaluator(net, device), "hip-winograd-mfma-f32"
+            return HipResNetEvaluator(net, device, engine_policy=True), "hip-winograd-mfma-f32"
         except (ImportError, hip.XqError):
             if kind == "hip":
                 raise

@@ -2,6 +2,12 @@
 through `xq_wino_conv3x3` -- fused Winograd F(2x2,3x3) on the fp32 MFMA with folded-BN bias, ReLU and the skip
 connection in its epilogue -- on NHWC activations that ping-pong between three preallocated buffers.  The 15->C input
 convolution (1.7 % of the FLOPs) and the two heads stay on the ROCm library via torch.  fp32 throughout.
+
+Engine-facing calls (`engine_policy=True`, what `evaluator.make_evaluator` builds) compute the policy head's 2880 -> 8100
+layer only for the 2 550 action ids some piece can ever move along (`sample_format.reachable_actions`) and leave -inf
+in the other columns: the softmax the engine takes over the row and renormalises over the legal moves
+(mcts.py:157-188) is unchanged, the GEMM is 3.2x smaller.  `predict()` -- the reference's single-position protocol, whose
+output is a distribution over all 8 100 ids -- always uses the full layer.
 """
 from __future__ import annotations
 
@@ -10,10 +16,12 @@ import torch
 
 from . import hip
 from .model import InferenceNet, XiangqiNet
+from .sample_format import reachable_actions
 
 
 class HipResNetEvaluator:
-    def __init__(self, net: XiangqiNet, device="cuda"):
+    def __init__(self, net: XiangqiNet, device="cuda", engine_policy: bool = False):
+        self.engine_policy = bool(engine_policy)
         if net.num_channels % 64 or 8 % (net.num_channels // 64):
             raise hip.XqError("HipResNetEvaluator: channels must be 64, 128, 256 or 512")
         lib = hip.lib()
@@ -25,6 +33,8 @@ class HipResNetEvaluator:
         torch.backends.cuda.matmul.allow_tf32 = False
         torch.backends.cudnn.allow_tf32 = False
         self._bufs = None
+        self._logits = None          # engine_policy: persistent [B, 8100] rows, -inf outside the reachable columns
+        self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []
         self.update(net)
@@ -44,6 +54,7 @@ class HipResNetEvaluator:
         fp = ref.fc_p_w.view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
         fv = ref.fc_v1_w.view(-1, 4, 90).permute(0, 2, 1).reshape(-1, 360)
         self.fc_p_w, self.fc_p_b = dv(fp), dv(ref.fc_p_b)
+        self.fc_pr_w, self.fc_pr_b = dv(self.fc_p_w[self.reach]), dv(self.fc_p_b[self.reach])
         self.fc_v1_w, self.fc_v1_b = dv(fv), dv(ref.fc_v1_b)
         self.fc_v2_w, self.fc_v2_b = dv(ref.fc_v2_w), dv(ref.fc_v2_b)
 
@@ -53,7 +64,7 @@ class HipResNetEvaluator:
         return self._bufs
 
     @torch.no_grad()
-    def __call__(self, x: torch.Tensor):
+    def __call__(self, x: torch.Tensor, full_policy: bool = False):
         F = torch.nn.functional
         b = x.shape[0]
         h0 = F.conv2d(x.contiguous(memory_format=torch.channels_last), self.w_in, None, padding=1)   # NHWC memory
@@ -69,7 +80,13 @@ class HipResNetEvaluator:
             h = o
         rows = h.view(b * 90, self.C)
         p = hip.bias_act_(rows @ self.w_p.t(), self.b_p)             # 1x1 conv == GEMM over NHWC rows
-        logits = F.linear(p.view(b, 2880), self.fc_p_w, self.fc_p_b)
+        if self.engine_policy and not full_policy:
+            if self._logits is None or self._logits.shape[0] != b:
+                self._logits = torch.full((b, hip.ACTION_SPACE), float("-inf"), dtype=torch.float32, device=self.device)
+            logits = self._logits                                    # consumed by xq_engine_expand before the next call
+            logits[:, self.reach] = F.linear(p.view(b, 2880), self.fc_pr_w, self.fc_pr_b)
+        else:
+            logits = F.linear(p.view(b, 2880), self.fc_p_w, self.fc_p_b)
         v = hip.bias_act_(rows @ self.w_v.t(), self.b_v)
         v = F.relu(F.linear(v.view(b, 360), self.fc_v1_w, self.fc_v1_b))
         value = torch.tanh(F.linear(v, self.fc_v2_w, self.fc_v2_b))
@@ -107,5 +124,5 @@ class HipResNetEvaluator:
 
     def predict(self, state: np.ndarray, device=None):
         x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
-        logits, value = self(x)
+        logits, value = self(x, full_policy=True)
         return torch.softmax(logits, dim=1).squeeze(0).cpu().numpy(), float(value.item())

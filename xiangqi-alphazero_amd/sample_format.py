@@ -91,3 +91,22 @@ def to_reference_tuples(samples: np.ndarray, results: np.ndarray, late_temperatu
                 all_data.append((fs, fp, z))
         per_game.append((int(r["winner"]), int(r["steps"]), len(mine)))
     return all_data, per_game
+
+
+def reachable_actions() -> np.ndarray:
+    """Sorted action ids (from*90 + to) along which SOME piece on SOME square can ever move, whatever the position:
+    rook/cannon/pawn/king lines (same row or column), knight jumps, one- and two-step diagonals (advisor, elephant;
+    taken on the whole board, a superset of game.py:262-452 / game_core.pyx:185-330 for any placement, legal or not).
+    2 550 of the 8 100 ids: the policy head only has to produce these columns for the engine, every other logit can
+    never belong to a legal move."""
+    acts = []
+    for fr in range(10):
+        for fc in range(9):
+            for tr in range(10):
+                for tc in range(9):
+                    dr, dc = abs(tr - fr), abs(tc - fc)
+                    if (dr, dc) == (0, 0):
+                        continue
+                    if dr == 0 or dc == 0 or (dr, dc) in ((1, 2), (2, 1), (1, 1), (2, 2)):
+                        acts.append((fr * 9 + fc) * 90 + tr * 9 + tc)
+    return np.array(sorted(acts), dtype=np.int64)
