@@ -104,7 +104,7 @@ def test_bias_act_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,b", [(64, 3), (64, 41), (128, 64), (256, 100), (256, 1)])
+@pytest.mark.parametrize("c,b", [(64, 3), (64, 41), (128, 64), (256, 100), (256, 1), (512, 7), (256, 333)])
 def test_winograd_conv_kernel_vs_torch(c, b):
     """xq_wino_conv3x3 (fp32 MFMA, fused epilogue) against torch conv2d fp32 on the same inputs."""
     import torch
