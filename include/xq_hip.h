@@ -197,13 +197,15 @@ int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, 
                 int relu, void *stream);
 
 /* 3x3 convolution, stride 1, pad 1, C -> C channels (ResBlock.conv1/conv2 with BatchNorm folded, model.py:25-36)
- * as fused Winograd F(2x2,3x3) on the fp32 MFMA:  y = act(conv(x) + bias (+ residual)).
+ * as fused Winograd F(2x3,3x3) -- F(2,3) along the 10 rows, F(3,3) at the points 0, +-1, 2, inf along the 9 columns -- on
+ * the fp32 MFMA:  y = act(conv(x) + bias (+ residual)).
  *   dev_x, dev_y, dev_residual : float32[batch][90][channels] (NHWC; y must not alias x or residual)
- *   dev_u : pre-transformed weights, float32[C/64][C/8][16][2][64][4] with
- *           u[cog][chunk][4p+q][quad][co][j] = s_p (G g G^T)[p][q] for output channel 64*cog+co and input channel
- *           8*chunk+4*quad+j, g = the folded 3x3 filter (cross-correlation, as torch.nn.Conv2d), s_p = -1 for
- *           p = 2 and +1 otherwise (the kernel forms row 2 of B^T d with the opposite sign);
- *           xq_wino_weight_bytes(C) bytes.  channels in {64, 128, 256, 512}; batch*90*channels*4 < 2^32. */
+ *   dev_u : pre-transformed weights, float32[C/64][C/8][20][2][64][4] with
+ *           u[cog][chunk][5p+j][quad][co][k] = s_p (G_r g G_c'^T)[p][j] for output channel 64*cog+co and input channel
+ *           8*chunk+4*quad+k, g = the folded 3x3 filter (cross-correlation, as torch.nn.Conv2d), G_r the F(2,3) matrix,
+ *           G_c' = diag(1/2, 1/2, 1/6, 1/6, 1) [[1,0,0],[1,1,1],[1,-1,1],[1,2,4],[0,0,1]], s_p = -1 for p = 2 and +1
+ *           otherwise (the kernel forms row 2 of B_r^T d with the opposite sign);
+ *           xq_wino_weight_bytes(C) = 80 C^2 bytes.  channels in {64, 128, 256, 512}; batch*90*channels*4 < 2^32. */
 size_t xq_wino_weight_bytes(int channels);
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
                     float *dev_y, int batch, int channels, int relu, void *stream);

@@ -170,6 +170,36 @@ void runmix1(const char *name, float *d, const float *g) {
     printf("1 wave/SIMD mix %3d %-46s %8.3f ms  %6.1f TFLOP/s  cycles/iter/SIMD@2.4GHz %.0f\n", MIX, name, ms, tf, ms * 1e-3 * 2.4e9 / iters);
 }
 
+
+// Dependent-accumulator distance: 32 MFMAs per iteration where MFMA i accumulates into acc[(i / RUN) % 8], i.e. RUN
+// back-to-back MFMAs on the same accumulator before moving on (RUN = 1: distance 8 as in k<>, RUN = 4: chains of four).
+template <int RUN>
+__global__ __launch_bounds__(512, 2) void kdep(float *out, int iters) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = tid * 0.001f, b = 1.0f + lane * 0.01f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[(i / RUN) & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[(i / RUN) & 7], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][7];
+    if (s == 1234.5f) out[tid] = s;
+}
+template <int RUN>
+void rundep(float *d) {
+    const int iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kdep<RUN><<<256, 512>>>(d, 10);
+    hipEventRecord(e0);
+    kdep<RUN><<<256, 512>>>(d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double tf = (double)256 * 8 * iters * 32 * 4096 / (ms * 1e-3) / 1e12;
+    printf("dependent chains of %d MFMAs on one accumulator (2 waves/SIMD): %8.3f ms  %6.1f TFLOP/s\n", RUN, ms, tf);
+}
+
 template <int MIX>
 void runmix16(const char *name, float *d, const float *g) {
     hipFuncSetAttribute((const void *)kmix16<MIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
@@ -261,5 +291,6 @@ int main() {
     runmix1<1 + 2 + 4 + 16>("LDS+VALU mix, no barrier", d, g);
     runmix1<1 + 2 + 4 + 8 + 16 + 32>("full chunk mix (no staging)", d, g);
     runmix1<1 + 2 + 4 + 8 + 16 + 32 + 64>("full chunk mix + staging", d, g);
+    rundep<1>(d); rundep<2>(d); rundep<4>(d); rundep<32>(d);
     return 0;
 }

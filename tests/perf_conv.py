@@ -32,6 +32,6 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 direct = 2.0 * B * 90 * 9 * C * C
-wino = 16 * 2.0 * ((B * 25 + 63) // 64 * 64) * C * C
+wino = 20 * 2.0 * ((B * 15 + 31) // 32 * 32) * C * C
 print("flags=%d " % FLAGS + "B=%d C=%d  %.3f ms  direct-equivalent %.1f TFLOP/s  MFMA (winograd flops) %.1f TFLOP/s = %.1f%% of 157.3"
       % (B, C, ms, direct / ms / 1e9, wino / ms / 1e9, wino / ms / 1e9 / 157.3 * 100))

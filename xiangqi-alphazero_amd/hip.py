@@ -215,15 +215,19 @@ def bias_act_(y: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = T
 
 def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:
     """Folded 3x3 filters float32[C,C,3,3] -> the kernel's pre-transformed layout (see include/xq_hip.h,
-    xq_wino_conv3x3): U = G g G^T per (co, ci), computed in float64, stored float32 [C/64][C/8][16][2][64][4]."""
+    xq_wino_conv3x3): U = s_p (G_r g G_c'^T)[p][j] per (co, ci) for the F(2,3) x F(3,3) transform, computed in float64,
+    stored float32 [C/64][C/8][20][2][64][4]."""
     c = w.shape[0]
     if w.shape != (c, c, 3, 3) or c % 64 or 8 % (c // 64):
         raise XqError("wino_transform_weights: [C,C,3,3] with C in {64,128,256,512} required")
-    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-    u = torch.einsum("pr,oirs,qs->pqoi", g, w.detach().to("cpu", torch.float64), g)      # [4,4,co,ci]
-    u[2] = -u[2]                    # the kernel forms row 2 of B^T d as d1 - d2 (the negative of the textbook row)
-    u = u.reshape(16, c // 64, 64, c // 8, 2, 4)                                           # xi, cog, co, chunk, quad, j
-    u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, j
+    gr = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    # F(3,3) at the points 0, 1, -1, 2, inf; the kernel's B^T rows are the textbook ones times (2, 2, 6, 6, 1)
+    gc = torch.tensor([[1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 2.0, 4.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    gc = gc * torch.tensor([0.5, 0.5, 1.0 / 6.0, 1.0 / 6.0, 1.0], dtype=torch.float64)[:, None]
+    u = torch.einsum("pr,oirs,qs->pqoi", gr, w.detach().to("cpu", torch.float64), gc)      # [4,5,co,ci]
+    u[2] = -u[2]                    # the kernel forms row 2 of B_r^T d as d1 - d2 (the negative of the textbook row)
+    u = u.reshape(20, c // 64, 64, c // 8, 2, 4)                                           # xi, cog, co, chunk, quad, k
+    u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, k
     return u.to(w.device)
 
 
@@ -237,3 +241,4 @@ def wino_conv3x3(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torc
                                 None if residual is None else residual.data_ptr(), out.data_ptr(), b, c, int(relu),
                                 stream_ptr(x.device)), "xq_wino_conv3x3")
     return out
+

@@ -1,5 +1,5 @@
 """B2 evaluator on the hand-written kernels: the residual tower (model.py:99-101; >97 % of the FLOPs at 256x10) runs
-through `xq_wino_conv3x3` -- fused Winograd F(2x2,3x3) on the fp32 MFMA with folded-BN bias, ReLU and the skip
+through `xq_wino_conv3x3` -- fused Winograd F(2x3,3x3) on the fp32 MFMA with folded-BN bias, ReLU and the skip
 connection in its epilogue -- on NHWC activations that ping-pong between three preallocated buffers.  The 15->C input
 convolution (1.7 % of the FLOPs) and the two heads stay on the ROCm library via torch.  fp32 throughout.
 
@@ -112,10 +112,10 @@ class HipResNetEvaluator:
         ms = [a.elapsed_time(b) for a, b in self._events]
         avg = sum(ms) / len(ms)
         direct = 2.0 * 90 * 9 * self.C * self.C * batch
-        tiles = (batch * 25 + 31) // 32 * 32
-        mfma = 16 * 2.0 * tiles * self.C * self.C
+        tiles = (batch * 15 + 31) // 32 * 32
+        mfma = 20 * 2.0 * tiles * self.C * self.C
         ach = direct / (avg * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "k_wino_conv (fused Winograd F(2x2,3x3) 3x3 conv, fp32 MFMA 32x32x2)",
+        return {"bound": "mfma", "kernel": "k_wino_conv (fused Winograd F(2x3,3x3) 3x3 conv, fp32 MFMA 32x32x2)",
                 "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
                 "launches_timed": len(ms), "avg_launch_ms": round(avg, 4),
                 "algorithmic_flops_per_launch": direct, "mfma_flops_per_launch": mfma,
