@@ -56,7 +56,9 @@ constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;      // one 8-channel chunk of wei
 constexpr int XSTRIDE = 48;                          // bytes per staged position: 8 channels + 16 B pad
 constexpr int XPOS = (4 * 11 + 1) * 10 + 1;     // 4 boards with halo
 constexpr int XRAW = (XPOS + 1) * XSTRIDE;         // + one dump position
-constexpr int E_BYTES = 4 * 3 * TILES * 32 * 4;    // epilogue exchange for one 32-channel half: [row p][b][tile][co]
+constexpr int ESTR = 36;                             // floats per tile row of an exchange plane (32 + 4: the two
+                                                     // lane halves of an accumulator write land on different banks)
+constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
@@ -221,15 +223,18 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int o = tid * 16; o < 2 * XRAW; o += 256 * 16) *(f32x4 *)(Xr + o) = z;
     }
-    load_x(0);
-    __syncthreads();
+    f32x4 x1[2];
+    load_x(0);                                        // chunks 0 and 1 are fetched together: one HBM latency, not two
+#pragma unroll
+    for (int k = 0; k < 2; ++k) x1[k] = buf_ld4(xrs, xgk[k], 32);
+    __syncthreads();                                  // zero fill before the first stores
     store_x(0);
-    load_x(1);
-    store_x(1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) *(f32x4 *)(Xr + XRAW + xl[k]) = x1[k];
     load_x(2);
     __syncthreads();
     transform0();
-    __syncthreads();
+    __syncthreads();                                  // chunk 0 stores into the buffer transform0 just read
 
     // ---- main loop: chunk c multiplies (a, fragments) of chunk c, transforms chunk c+1 out of buffer (c+1)&1,
     // stores chunk c+2 into buffer c&1 and fetches chunk c+3; one barrier per chunk
@@ -241,8 +246,22 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     }
 
     // ---- epilogue: Y = A_r^T M A_c, bias, residual, ReLU; one 32-channel half at a time through LDS --------------
-    float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co]
+    // Output coordinates and the residual loads come first: their HBM latency hides behind the register reduction
+    // and the exchange (the main loop's operand registers are dead by now).
     const int c4 = tid & 7, co = c4 * 4;
+    size_t oaddr[6];
+    f32x4 resv[6];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int pidx = it * 32 + (tid >> 3);                   // 0..191 = (tile, ya, yb)
+        const int tile = pidx / 6, r6 = pidx - tile * 6, ya = r6 / 3, yb = r6 - ya * 3;
+        const int g = t0 + tile;
+        const int bd = g / 15, t2 = g - bd * 15, ty2 = t2 / 3, tx2 = t2 - ty2 * 3;
+        oaddr[it] = g < T ? ((size_t)bd * 90 + (2 * ty2 + ya) * 9 + 3 * tx2 + yb) * C + cog * NCO + co : (size_t)-1;
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        resv[it] = (R && oaddr[it] != (size_t)-1) ? *(const f32x4 *)(R + oaddr[it]) : z;
+    }
+    float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const f32x16 m0 = acc[0][n], m1 = acc[1][n], m2 = acc[2][n], m3 = acc[3][n], m4 = acc[4][n];
@@ -252,31 +271,32 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tile = (e & 3) + 8 * (e >> 2) + 4 * h;
-            E[((wp * 3 + 0) * TILES + tile) * 32 + l31] = y0[e];
-            E[((wp * 3 + 1) * TILES + tile) * 32 + l31] = y1[e];
-            E[((wp * 3 + 2) * TILES + tile) * 32 + l31] = y2[e];
+            E[((wp * 3 + 0) * TILES + tile) * ESTR + l31] = y0[e];
+            E[((wp * 3 + 1) * TILES + tile) * ESTR + l31] = y1[e];
+            E[((wp * 3 + 2) * TILES + tile) * ESTR + l31] = y2[e];
         }
         __syncthreads();
         const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
-            const int pidx = it * 32 + (tid >> 3);               // 0..191 = (tile, ya, yb)
+            const int pidx = it * 32 + (tid >> 3);
             const int tile = pidx / 6, r6 = pidx - tile * 6, ya = r6 / 3, yb = r6 - ya * 3;
-            const int g = t0 + tile;
-            if (g >= T) continue;
-            const int bd = g / 15, t2 = g - bd * 15, ty2 = t2 / 3, tx2 = t2 - ty2 * 3;
-            const size_t oaddr = ((size_t)bd * 90 + (2 * ty2 + ya) * 9 + 3 * tx2 + yb) * C + cog * NCO + 32 * n + co;
-            const float *e0 = E + (yb * TILES + tile) * 32 + co;
-            const int pstride = 3 * TILES * 32;
+            if (oaddr[it] == (size_t)-1) continue;
+            const float *e0 = E + (yb * TILES + tile) * ESTR + co;
+            const int pstride = 3 * TILES * ESTR;        // next Winograd row p
             f32x4 y;
             if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
             else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
-            y = y + bv;
-            if (R) y = y + *(const f32x4 *)(R + oaddr);
+            y = y + bv + resv[it];
             if (relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
-            *(f32x4 *)(Y + oaddr) = y;
+            *(f32x4 *)(Y + oaddr[it] + 32 * n) = y;
         }
-        __syncthreads();
+        if (n == 0) {
+#pragma unroll
+            for (int it = 0; it < 6; ++it)            // residual of the second half: in flight during its exchange
+                if (R && oaddr[it] != (size_t)-1) resv[it] = *(const f32x4 *)(R + oaddr[it] + 32);
+            __syncthreads();                          // the second half overwrites the planes
+        }
     }
 }
 
