@@ -246,20 +246,20 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     }
 
     // ---- epilogue: Y = A_r^T M A_c, bias, residual, ReLU; one 32-channel half at a time through LDS --------------
-    // Output coordinates and the residual loads come first: their HBM latency hides behind the register reduction
-    // and the exchange (the main loop's operand registers are dead by now).
-    const int c4 = tid & 7, co = c4 * 4;
-    size_t oaddr[6];
+    // Thread (tile = tid >> 3, channel quad = tid & 7) writes the six pixels of its tile, so the pixel inside the tile is
+    // a compile-time constant of the unrolled loop.  The residual loads come first: their HBM latency hides behind the
+    // register reduction and the exchange (the main loop's operand registers are dead by now).
+    const int etile = tid >> 3, co = (tid & 7) * 4;
+    const int eg = t0 + etile;
+    const bool eok = eg < T;
+    const int ebd = eg / 15, et2 = eg - ebd * 15, ety = et2 / 3, etx = et2 - ety * 3;
+    const size_t obase = eok ? ((size_t)ebd * 90 + (2 * ety) * 9 + 3 * etx) * C + cog * NCO + co : 0;
+    const bool has_r = R != nullptr;
     f32x4 resv[6];
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
-        const int pidx = it * 32 + (tid >> 3);                   // 0..191 = (tile, ya, yb)
-        const int tile = pidx / 6, r6 = pidx - tile * 6, ya = r6 / 3, yb = r6 - ya * 3;
-        const int g = t0 + tile;
-        const int bd = g / 15, t2 = g - bd * 15, ty2 = t2 / 3, tx2 = t2 - ty2 * 3;
-        oaddr[it] = g < T ? ((size_t)bd * 90 + (2 * ty2 + ya) * 9 + 3 * tx2 + yb) * C + cog * NCO + co : (size_t)-1;
         f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        resv[it] = (R && oaddr[it] != (size_t)-1) ? *(const f32x4 *)(R + oaddr[it]) : z;
+        resv[it] = (has_r && eok) ? *(const f32x4 *)(R + obase + ((it / 3) * 9 + it % 3) * C) : z;
     }
     float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats
 #pragma unroll
@@ -277,24 +277,29 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         }
         __syncthreads();
         const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
+        f32x4 yv[6];
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
-            const int pidx = it * 32 + (tid >> 3);
-            const int tile = pidx / 6, r6 = pidx - tile * 6, ya = r6 / 3, yb = r6 - ya * 3;
-            if (oaddr[it] == (size_t)-1) continue;
-            const float *e0 = E + (yb * TILES + tile) * ESTR + co;
+            const int ya = it / 3, yb = it % 3;
+            const float *e0 = E + (yb * TILES + etile) * ESTR + co;
             const int pstride = 3 * TILES * ESTR;        // next Winograd row p
             f32x4 y;
             if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
             else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
             y = y + bv + resv[it];
             if (relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
-            *(f32x4 *)(Y + oaddr[it] + 32 * n) = y;
+            yv[it] = y;
+        }
+        if (eok) {
+#pragma unroll
+            for (int it = 0; it < 6; ++it) *(f32x4 *)(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C) = yv[it];
         }
         if (n == 0) {
+            if (has_r && eok) {
 #pragma unroll
-            for (int it = 0; it < 6; ++it)            // residual of the second half: in flight during its exchange
-                if (R && oaddr[it] != (size_t)-1) resv[it] = *(const f32x4 *)(R + oaddr[it] + 32);
+                for (int it = 0; it < 6; ++it)        // residual of the second half: in flight during its exchange
+                    resv[it] = *(const f32x4 *)(R + obase + 32 + ((it / 3) * 9 + it % 3) * C);
+            }
             __syncthreads();                          // the second half overwrites the planes
         }
     }
