@@ -78,6 +78,26 @@ __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
     asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a.z, a.w}), "v"(f32x2{b.z, b.w}));
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
+__device__ __forceinline__ float relu1(float x) {                // one v_max_f32 (fmaxf adds a canonicalising max)
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma2(f32x2 x, f32x2 c, f32x2 y) {
+    f32x2 r;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(c), "v"(y));
+    return r;
+}
 // x * c + y  /  x * c - y
 __device__ __forceinline__ f32x4 pk_fma4(f32x4 x, f32x2 c, f32x4 y) {
     f32x2 lo, hi;
@@ -118,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     const int tb1 = tbase + (wp == 0 ? 0 : 10) * XSTRIDE, tb2 = tbase + (wp == 3 ? 30 : 20) * XSTRIDE;
     const float sg = wp == 1 ? 1.0f : -1.0f;
     const f32x2 sgn = {sg, sg};
-    const f32x2 two = {2.0f, 2.0f}, three = {3.0f, 3.0f}, mtwo = {-2.0f, -2.0f};
+    const f32x2 two = {2.0f, 2.0f}, three = {3.0f, 3.0f}, mtwo = {-2.0f, -2.0f}, four = {4.0f, 4.0f};
 
     // staging role: a contiguous run of positions (first tile's halo row .. last tile's), 2 x 16 B per position and chunk
     const int tl = (t0 + TILES - 1 < T ? t0 + TILES - 1 : T - 1);
@@ -145,13 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     // B fragment (q, nt): lane (h, n) needs U[5 wp + q][8 chunk + 4h + j][64 cog + 32 nt + n], j = 0..3
     const unsigned ul = ((wp * 5 * 2 + h) * NCO + l31) * 16;
 
-    f32x16 acc[5][2];
-#pragma unroll
-    for (int q = 0; q < 5; ++q)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[q][n][e] = 0.0f;
+    f32x16 acc[5][2];                                 // first written by chunk 0 (its MFMAs start from a zero C operand)
 
     f32x4 xreg[2];
     auto load_x = [&](int chunk) __attribute__((always_inline)) {
@@ -183,8 +197,9 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         a[4] = pk_fma4(t, mtwo, pk_sub4(w[4], w[2]));
     };
     // One chunk: 40 MFMAs (10 weight fragments x 4 k-steps); the transform of the next chunk is threaded through.
-    auto chunk_body = [&](int nchunk_u, int lchunk, auto xo_tag, int stage) __attribute__((always_inline)) {
+    auto chunk_body = [&](int nchunk_u, int lchunk, auto xo_tag, int stage, auto first_tag) __attribute__((always_inline)) {
         constexpr int XO = decltype(xo_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
         f32x4 d1, d2, w1, w3, w2, w0, t, e, fm, v0;
 #pragma unroll
         for (int f = 0; f < 10; ++f) {
@@ -197,7 +212,12 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
             if (f == 8) a[0] = v0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], acc[q][nt], 0, 0, 0);
+                if (FIRST && jj == 0) {
+                    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], zero, 0, 0, 0);
+                } else {
+                    acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], acc[q][nt], 0, 0, 0);
+                }
                 if (jj == 1) __builtin_amdgcn_sched_barrier(0);
             }
             // weights: fragment f+5 replaces this one (f < 5: later in this chunk, else the next chunk's f-5)
@@ -238,10 +258,14 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
 
     // ---- main loop: chunk c multiplies (a, fragments) of chunk c, transforms chunk c+1 out of buffer (c+1)&1,
     // stores chunk c+2 into buffer c&1 and fetches chunk c+3; one barrier per chunk
-    for (int c = 0; c < NCH; c += 2) {
-        chunk_body(c + 1, c, std::integral_constant<int, XRAW>{}, c + 2);
+    chunk_body(1, 0, std::integral_constant<int, XRAW>{}, 2, std::true_type{});
+    __syncthreads();
+    chunk_body(2, 1, std::integral_constant<int, 0>{}, 3, std::false_type{});
+    __syncthreads();
+    for (int c = 2; c < NCH; c += 2) {
+        chunk_body(c + 1, c, std::integral_constant<int, XRAW>{}, c + 2, std::false_type{});
         __syncthreads();
-        chunk_body(c + 2 < NCH ? c + 2 : c + 1, c + 1, std::integral_constant<int, 0>{}, c + 3);
+        chunk_body(c + 2 < NCH ? c + 2 : c + 1, c + 1, std::integral_constant<int, 0>{}, c + 3, std::false_type{});
         __syncthreads();
     }
 
@@ -262,18 +286,28 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         resv[it] = (has_r && eok) ? *(const f32x4 *)(R + obase + ((it / 3) * 9 + it % 3) * C) : z;
     }
     float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats
+    float *ew = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;        // + compile-time offsets: immediates of the LDS ops
+    const float *er = E + etile * ESTR + co;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const f32x16 m0 = acc[0][n], m1 = acc[1][n], m2 = acc[2][n], m3 = acc[3][n], m4 = acc[4][n];
-        const f32x16 y0 = m0 + m1 + m2 + m3;
-        const f32x16 y1 = m1 - m2 + 2.0f * m3;
-        const f32x16 y2 = m1 + m2 + 4.0f * m3 + m4;
+        // column half of the inverse transform on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3,
+        // y2 = m1+m2+4 m3+m4
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int tile = (e & 3) + 8 * (e >> 2) + 4 * h;
-            E[((wp * 3 + 0) * TILES + tile) * ESTR + l31] = y0[e];
-            E[((wp * 3 + 1) * TILES + tile) * ESTR + l31] = y1[e];
-            E[((wp * 3 + 2) * TILES + tile) * ESTR + l31] = y2[e];
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 m0 = {acc[0][n][e], acc[0][n][e + 1]}, m1 = {acc[1][n][e], acc[1][n][e + 1]};
+            const f32x2 m2 = {acc[2][n][e], acc[2][n][e + 1]}, m3 = {acc[3][n][e], acc[3][n][e + 1]};
+            const f32x2 m4 = {acc[4][n][e], acc[4][n][e + 1]};
+            const f32x2 s12 = pk_add2(m1, m2);
+            const f32x2 y0 = pk_add2(pk_add2(m0, m3), s12);
+            const f32x2 y1 = pk_fma2(m3, two, pk_sub2(m1, m2));
+            const f32x2 y2 = pk_add2(pk_fma2(m3, four, s12), m4);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int tile = ((e + k) & 3) + 8 * ((e + k) >> 2);     // + 4 h (in ew)
+                ew[(0 * TILES + tile) * ESTR] = y0[k];
+                ew[(1 * TILES + tile) * ESTR] = y1[k];
+                ew[(2 * TILES + tile) * ESTR] = y2[k];
+            }
         }
         __syncthreads();
         const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
@@ -281,13 +315,13 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
             const int ya = it / 3, yb = it % 3;
-            const float *e0 = E + (yb * TILES + etile) * ESTR + co;
+            const float *e0 = er + yb * TILES * ESTR;
             const int pstride = 3 * TILES * ESTR;        // next Winograd row p
             f32x4 y;
             if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
             else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
             y = y + bv + resv[it];
-            if (relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
+            if (relu) { y.x = relu1(y.x); y.y = relu1(y.y); y.z = relu1(y.z); y.w = relu1(y.w); }
             yv[it] = y;
         }
         if (eok) {
