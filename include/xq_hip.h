@@ -196,6 +196,21 @@ int xq_engine_read_root(const xq_engine *eng, int slot, uint16_t *actions, int32
 int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, long long rows, int channels,
                 int relu, void *stream);
 
+/* Input convolution (model.py:87-93: Conv2d(15, C, 3, padding=1), BatchNorm folded, ReLU) straight from the encoder's
+ * planes:  y = relu(conv(planes) + bias).  Exact for any input; fast because the planes are sparse (zero inputs are skipped).
+ *   dev_planes : float32[games][15][10][9] (xq_engine_select's nn_input);  dev_y : float32[games][90][channels] (NHWC);
+ *   dev_wt : float32[135][channels], dev_wt[plane*9 + ky*3 + kx][co] = folded filter w[co][plane][ky][kx];
+ *   dev_bias : float32[channels].  channels % 4 == 0. */
+int xq_stem_conv(const float *dev_planes, const float *dev_wt, const float *dev_bias, float *dev_y, int games,
+                 int channels, void *stream);
+
+/* Both heads' 1x1 convolutions (model.py:43-62: policy Conv2d(C,32,1), value Conv2d(C,4,1), BatchNorm folded, ReLU) in one
+ * pass over the tower output:  out[r][o] = relu(bias[o] + sum_c h[r][c] w[o][c]),  o < 36.
+ *   dev_h : float32[rows][channels] (NHWC rows);  dev_w : float32[36][channels], rows 0-31 policy, 32-35 value;
+ *   dev_bias : float32[36];  dev_p : float32[rows][32];  dev_v : float32[rows][4].  channels % 16 == 0, <= 1024. */
+int xq_heads_1x1(const float *dev_h, const float *dev_w, const float *dev_bias, float *dev_p, float *dev_v,
+                 long long rows, int channels, void *stream);
+
 /* 3x3 convolution, stride 1, pad 1, C -> C channels (ResBlock.conv1/conv2 with BatchNorm folded, model.py:25-36)
  * as fused Winograd F(2x3,3x3) -- F(2,3) along the 10 rows, F(3,3) at the points 0, +-1, 2, inf along the 9 columns -- on
  * the fp32 MFMA:  y = act(conv(x) + bias (+ residual)).

@@ -104,6 +104,48 @@ def test_bias_act_kernel():
 
 
 @pytest.mark.gpu
+def test_stem_conv_kernel():
+    """xq_stem_conv against a float64 convolution: real encoder planes (sparse, one-hot) and dense random inputs (the
+    kernel skips zeros but must be exact for any input)."""
+    import torch
+    import torch.nn.functional as F
+    from xiangqi_alphazero_amd import hip
+    _, states = _states()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    dense = torch.randn(5, 15, 10, 9, generator=g)
+    dense[:, 3] = 0.0
+    for c in (64, 128, 256, 512):
+        w = torch.randn(c, 15, 3, 3, generator=g) * 0.2
+        b = torch.randn(c, generator=g) * 0.1
+        wt = hip.stem_weights(w).cuda()
+        assert wt.shape == (135, c)
+        for planes in (torch.from_numpy(states), dense, torch.zeros(2, 15, 10, 9)):
+            out = torch.full((planes.shape[0], 90, c), float("nan"), device="cuda")
+            hip.stem_conv(planes.cuda(), wt, b.cuda(), out)
+            want = torch.relu(F.conv2d(planes.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1).reshape(-1, 90, c)
+            np.testing.assert_allclose(out.double().cpu().numpy(), want.numpy(), rtol=0, atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_heads_1x1_kernel():
+    """xq_heads_1x1 (both heads' 1x1 convolutions + bias + ReLU in one pass) against a float64 matmul."""
+    import torch
+    from xiangqi_alphazero_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for rows, c in ((1, 64), (90 * 3 + 7, 128), (90 * 41, 256), (16, 512), (90 * 8, 256)):
+        h = torch.relu(torch.randn(rows, c, generator=g)).cuda()
+        w = (torch.randn(36, c, generator=g) * (2.0 / c) ** 0.5).cuda()
+        b = (torch.randn(36, generator=g) * 0.1).cuda()
+        p, v = hip.heads_1x1(h, w, b)
+        want = torch.relu(h.double() @ w.double().t() + b.double())
+        assert p.shape == (rows, 32) and v.shape == (rows, 4)
+        np.testing.assert_allclose(p.double().cpu().numpy(), want[:, :32].cpu().numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(v.double().cpu().numpy(), want[:, 32:].cpu().numpy(), rtol=0, atol=5e-6)
+    with pytest.raises(hip.XqError):
+        hip.heads_1x1(h, w[:35], b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,b", [(64, 3), (64, 41), (128, 64), (256, 100), (256, 1), (512, 7), (256, 333)])
 def test_winograd_conv_kernel_vs_torch(c, b):
     """xq_wino_conv3x3 (fp32 MFMA, fused epilogue) against a float64 convolution of the same unit-scale inputs.  The

@@ -77,6 +77,111 @@ __global__ __launch_bounds__(256) void k_bias_act(float4 *__restrict__ y, const 
     }
 }
 
+
+// Both heads' 1x1 convolutions in ONE pass over the tower output (model.py:43-62: policy Conv2d(C,32,1) and value
+// Conv2d(C,4,1), BatchNorm folded, ReLU): out[r][o] = relu(b[o] + sum_c h[r][c] W[o][c]) for the 36 output channels.
+// HBM-bound (reads 4 C bytes per position row once instead of twice, writes 144); the library path was two GEMMs +
+// two epilogue launches.  A wave takes 16 rows at a time: lane (r = lane >> 2, q = lane & 3) owns channels
+// {16 k + 4 q + j} of row r (four lanes read 64 contiguous bytes), multiplies them with the weights broadcast from LDS,
+// and the four lanes of a row are summed with two butterfly steps.
+constexpr int HEAD_OUT = 36;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_heads_1x1(const float *__restrict__ H, const float *__restrict__ W,
+                                                   const float *__restrict__ bias, float *__restrict__ P,
+                                                   float *__restrict__ V, long long rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Ws = (float *)smem;                         // [36][C]
+    for (int i = threadIdx.x * 4; i < HEAD_OUT * C; i += 256 * 4) *(float4 *)(Ws + i) = *(const float4 *)(W + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane >> 2, q = lane & 3;
+    const int nk = C / 16;
+    const long long n_batches = (rows + 15) / 16;
+    for (long long bt = (long long)blockIdx.x * 4 + wave; bt < n_batches; bt += (long long)gridDim.x * 4) {
+        const long long row = bt * 16 + r;
+        const bool ok = row < rows;
+        const float *hp = H + (ok ? row : 0) * C + 4 * q;
+        f32x2 acc2[HEAD_OUT];                           // even / odd channel partial sums: packed FMAs
+#pragma unroll
+        for (int o = 0; o < HEAD_OUT; ++o) acc2[o] = f32x2{0.0f, 0.0f};
+        float4 hv = *(const float4 *)hp;
+        for (int k = 0; k < nk; ++k) {
+            const f32x2 c01 = {hv.x, hv.y}, c23 = {hv.z, hv.w};
+            if (k + 1 < nk) hv = *(const float4 *)(hp + 16 * (k + 1));
+            const float *wk = Ws + 16 * k + 4 * q;
+#pragma unroll
+            for (int o = 0; o < HEAD_OUT; ++o) {
+                const float4 w = *(const float4 *)(wk + o * C);
+                acc2[o] = __builtin_elementwise_fma(c23, f32x2{w.z, w.w}, __builtin_elementwise_fma(c01, f32x2{w.x, w.y}, acc2[o]));
+            }
+        }
+        float acc[HEAD_OUT];
+#pragma unroll
+        for (int o = 0; o < HEAD_OUT; ++o) {
+            float v = acc2[o].x + acc2[o].y;
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            acc[o] = fmaxf(v + bias[o], 0.0f);
+        }
+        if (ok) {                                      // lane q of a row stores outputs 9q .. 9q+8
+#pragma unroll
+            for (int o = 0; o < HEAD_OUT; ++o) {
+                if (o / 9 == q) {
+                    if (o < 32) P[row * 32 + o] = acc[o];
+                    else V[row * 4 + (o - 32)] = acc[o];
+                }
+            }
+        }
+    }
+}
+
+
+// Input convolution (model.py:87-93: Conv2d(15, C, 3, padding=1), BatchNorm folded, ReLU) over the encoder's planes
+// float[G][15][90], output NHWC float[G][90][C].  The planes are one-hot piece maps plus a constant side plane, so of the
+// 135 (plane, tap) products of a position about a dozen are non-zero: a wave takes one position, its lanes test the 135
+// inputs (three ballots), and a scalar loop over the set bits accumulates x * w[entry][4 channels per lane] -- exact for
+// ANY input (zeros contribute nothing), ~10x fewer multiply-adds than the dense form, and the kernel is bound by the
+// 4 C bytes it writes per position.  Weights: float[135][C], entry = plane * 9 + (dy + 1) * 3 + (dx + 1).
+__global__ __launch_bounds__(256) void k_stem_conv(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                   const float *__restrict__ bias, float *__restrict__ Y, int C) {
+    __shared__ float xs[15 * 90];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 15 * 90; i += 256) xs[i] = X[(size_t)g * (15 * 90) + i];
+    __syncthreads();
+    for (int pos = wave; pos < 90; pos += 4) {
+        const int y = pos / 9, x = pos - y * 9;
+        float xv[3];
+        unsigned long long m[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = r * 64 + lane;
+            float v = 0.0f;
+            if (e < 135) {
+                const int plane = e / 9, t = e - plane * 9, ty = t / 3, yy = y + ty - 1, xx = x + (t - ty * 3) - 1;
+                if ((unsigned)yy < 10u && (unsigned)xx < 9u) v = xs[plane * 90 + yy * 9 + xx];
+            }
+            xv[r] = v;
+            m[r] = __ballot(v != 0.0f);
+        }
+        for (int c0 = lane * 4; c0 < C; c0 += 256) {
+            float4 acc = *(const float4 *)(bias + c0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                unsigned long long mm = m[r];                         // wave-uniform: a scalar loop over the set bits
+                while (mm) {
+                    const int b = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const float xe = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[r]), b));
+                    const float4 w = *(const float4 *)(Wt + (size_t)(r * 64 + b) * C + c0);
+                    acc.x = fmaf(xe, w.x, acc.x); acc.y = fmaf(xe, w.y, acc.y); acc.z = fmaf(xe, w.z, acc.z); acc.w = fmaf(xe, w.w, acc.w);
+                }
+            }
+            acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f);
+            *(float4 *)(Y + ((size_t)g * 90 + pos) * C + c0) = acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, long long rows, int channels,
@@ -99,5 +204,32 @@ extern "C" int xq_samples_to_batch(const void *dev_samples, const int32_t *dev_i
     if (n == 0) return XQ_OK;
     hipLaunchKernelGGL(k_samples_to_batch, dim3(n), dim3(64), 0, (hipStream_t)stream, (const xq_sample *)dev_samples, dev_index,
                        dev_flip, n, late_temperature, dev_states, dev_pi, dev_z);
+    return xq::launch_status();
+}
+
+extern "C" int xq_heads_1x1(const float *dev_h, const float *dev_w, const float *dev_bias, float *dev_p, float *dev_v,
+                            long long rows, int channels, void *stream) {
+    if (!dev_h || !dev_w || !dev_bias || !dev_p || !dev_v || rows < 0 || channels < 16 || channels % 16 || channels > 1024) return XQ_ERR_ARG;
+    if (((uintptr_t)dev_h | (uintptr_t)dev_w) & 15) return XQ_ERR_ARG;
+    if (rows == 0) return XQ_OK;
+    const int lds = HEAD_OUT * channels * 4;
+    static thread_local int attr_lds = 0;
+    if (lds > attr_lds) {
+        XQ_TRY(hipFuncSetAttribute((const void *)k_heads_1x1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_lds = lds;
+    }
+    long long blocks = ((rows + 15) / 16 + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_heads_1x1, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, dev_h, dev_w, dev_bias, dev_p,
+                       dev_v, rows, channels);
+    return xq::launch_status();
+}
+
+extern "C" int xq_stem_conv(const float *dev_planes, const float *dev_wt, const float *dev_bias, float *dev_y, int games,
+                            int channels, void *stream) {
+    if (!dev_planes || !dev_wt || !dev_bias || !dev_y || games < 0 || channels < 4 || channels % 4) return XQ_ERR_ARG;
+    if (((uintptr_t)dev_wt | (uintptr_t)dev_bias | (uintptr_t)dev_y) & 15) return XQ_ERR_ARG;
+    if (games == 0) return XQ_OK;
+    hipLaunchKernelGGL(k_stem_conv, dim3(games), dim3(256), 0, (hipStream_t)stream, dev_planes, dev_wt, dev_bias, dev_y, channels);
     return xq::launch_status();
 }

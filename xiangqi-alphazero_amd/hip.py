@@ -95,6 +95,8 @@ def lib():
     L.xq_engine_read_root.argtypes = [C.POINTER(Engine), i32, vp, vp, vp, vp, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     L.xq_bias_act.argtypes = [vp, vp, vp, C.c_longlong, i32, i32, vp]
+    L.xq_heads_1x1.argtypes = [vp, vp, vp, vp, vp, C.c_longlong, i32, vp]
+    L.xq_stem_conv.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.xq_samples_to_batch.argtypes = [vp, vp, vp, i32, C.c_double, vp, vp, vp, vp]
     L.xq_wino_weight_bytes.argtypes = [i32]
     L.xq_wino_weight_bytes.restype = C.c_size_t
@@ -107,7 +109,7 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_encode_batch", "xq_material_batch", "xq_apply_moves_batch", "xq_game_over_batch",
            "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
            "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
-           "xq_bias_act", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch"]
+           "xq_bias_act", "xq_stem_conv", "xq_heads_1x1", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch"]
 
 
 def check(rc: int, what: str):
@@ -211,6 +213,39 @@ def bias_act_(y: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = T
     check(lib().xq_bias_act(y.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(),
                             rows, c, int(relu), stream_ptr(y.device)), "xq_bias_act")
     return y
+
+
+def stem_weights(w_in: torch.Tensor) -> torch.Tensor:
+    """Folded input filters float32[C,15,3,3] -> float32[135, C] (entry = plane*9 + ky*3 + kx), see xq_stem_conv."""
+    c = w_in.shape[0]
+    if w_in.shape != (c, 15, 3, 3):
+        raise XqError("stem_weights: [C,15,3,3] required")
+    return w_in.detach().permute(1, 2, 3, 0).reshape(135, c).contiguous()
+
+
+def stem_conv(planes: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """planes float32[G,15,10,9] contiguous -> out float32[G,90,C] = relu(conv3x3(planes) + bias), NHWC."""
+    g = planes.shape[0]
+    c = wt.shape[1]
+    if planes.shape[1:] != (15, 10, 9) or not planes.is_contiguous() or wt.shape != (135, c) or not wt.is_contiguous() \
+            or out.shape != (g, 90, c) or not out.is_contiguous() or planes.dtype != torch.float32:
+        raise XqError("stem_conv: planes [G,15,10,9], wt [135,C], out [G,90,C] contiguous float32 required")
+    check(lib().xq_stem_conv(planes.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), g, c,
+                             stream_ptr(planes.device)), "xq_stem_conv")
+    return out
+
+
+def heads_1x1(rows: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
+    """rows float32[R, C] (NHWC rows of the tower output), w float32[36, C], bias float32[36] ->
+    (policy features float32[R, 32], value features float32[R, 4]), ReLU applied (model.py:43-62)."""
+    r, c = rows.shape
+    if not rows.is_contiguous() or w.shape != (36, c) or not w.is_contiguous() or bias.shape != (36,):
+        raise XqError("heads_1x1: rows [R,C] contiguous, w [36,C], bias [36] required")
+    p = torch.empty((r, 32), dtype=torch.float32, device=rows.device)
+    v = torch.empty((r, 4), dtype=torch.float32, device=rows.device)
+    check(lib().xq_heads_1x1(rows.data_ptr(), w.data_ptr(), bias.data_ptr(), p.data_ptr(), v.data_ptr(), r, c,
+                             stream_ptr(rows.device)), "xq_heads_1x1")
+    return p, v
 
 
 def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:

@@ -1,7 +1,8 @@
 """B2 evaluator on the hand-written kernels: the residual tower (model.py:99-101; >97 % of the FLOPs at 256x10) runs
 through `xq_wino_conv3x3` -- fused Winograd F(2x3,3x3) on the fp32 MFMA with folded-BN bias, ReLU and the skip
-connection in its epilogue -- on NHWC activations that ping-pong between three preallocated buffers.  The 15->C input
-convolution (1.7 % of the FLOPs) and the two heads stay on the ROCm library via torch.  fp32 throughout.
+connection in its epilogue -- on NHWC activations that ping-pong between preallocated buffers.  The 15->C input
+convolution reads the sparse encoder planes directly (`xq_stem_conv`), the heads' 1x1 convolutions are one pass over the
+tower output (`xq_heads_1x1`); only the heads' fully connected layers are ROCm library GEMMs.  fp32 throughout.
 
 Engine-facing calls (`engine_policy=True`, what `evaluator.make_evaluator` builds) compute the policy head's 2880 -> 8100
 layer only for the 2 550 action ids some piece can ever move along (`sample_format.reachable_actions`) and leave -inf
@@ -42,14 +43,15 @@ class HipResNetEvaluator:
     def update(self, net: XiangqiNet):
         ref = InferenceNet(net)
         dv = lambda t: t.to(self.device).contiguous()
-        self.w_in = ref.w_in.to(self.device).contiguous(memory_format=torch.channels_last)
+        self.wt_in = dv(hip.stem_weights(ref.w_in))                # [135, C] for xq_stem_conv
         self.b_in = dv(ref.b_in)
         self.blocks = []
         for i in range(self.num_res_blocks):
             self.blocks.append((hip.wino_transform_weights(getattr(ref, f"w1_{i}")).to(self.device), dv(getattr(ref, f"b1_{i}")),
                                 hip.wino_transform_weights(getattr(ref, f"w2_{i}")).to(self.device), dv(getattr(ref, f"b2_{i}"))))
-        self.w_p = dv(ref.w_p.view(ref.w_p.shape[0], -1)); self.b_p = dv(ref.b_p)
-        self.w_v = dv(ref.w_v.view(ref.w_v.shape[0], -1)); self.b_v = dv(ref.b_v)
+        # both heads' 1x1 convolutions as one [36, C] matrix: rows 0-31 policy, 32-35 value (xq_heads_1x1)
+        self.w_pv = dv(torch.cat([ref.w_p.view(ref.w_p.shape[0], -1), ref.w_v.view(ref.w_v.shape[0], -1)], 0))
+        self.b_pv = dv(torch.cat([ref.b_p, ref.b_v], 0))
         # heads consume NHWC rows: permute the FC weights once from the reference's (c, h, w) flatten order to (hw, c)
         fp = ref.fc_p_w.view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
         fv = ref.fc_v1_w.view(-1, 4, 90).permute(0, 2, 1).reshape(-1, 360)
@@ -60,17 +62,15 @@ class HipResNetEvaluator:
 
     def _buffers(self, b):
         if self._bufs is None or self._bufs[0].shape[0] != b:
-            self._bufs = [torch.empty((b, 90, self.C), dtype=torch.float32, device=self.device) for _ in range(3)]
+            self._bufs = [torch.empty((b, 90, self.C), dtype=torch.float32, device=self.device) for _ in range(4)]
         return self._bufs
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, full_policy: bool = False):
         F = torch.nn.functional
         b = x.shape[0]
-        h0 = F.conv2d(x.contiguous(memory_format=torch.channels_last), self.w_in, None, padding=1)   # NHWC memory
-        hip.bias_act_(h0, self.b_in)
-        h = h0.permute(0, 2, 3, 1).reshape(b, 90, self.C)           # view: channels-last memory is [B,10,9,C]
-        t1, t2, t3 = self._buffers(b)
+        t0, t1, t2, t3 = self._buffers(b)
+        h = hip.stem_conv(x.contiguous(), self.wt_in, self.b_in, t0)  # sparse input planes -> NHWC activations
         free = [t1, t2, t3]
         for u1, b1, u2, b2 in self.blocks:
             y = next(t for t in free if t.data_ptr() != h.data_ptr())
@@ -79,7 +79,7 @@ class HipResNetEvaluator:
             self._conv(y, u2, b2, o, h)
             h = o
         rows = h.view(b * 90, self.C)
-        p = hip.bias_act_(rows @ self.w_p.t(), self.b_p)             # 1x1 conv == GEMM over NHWC rows
+        p, v = hip.heads_1x1(rows, self.w_pv, self.b_pv)             # both 1x1 convolutions + bias + ReLU, one pass over h
         if self.engine_policy and not full_policy:
             if self._logits is None or self._logits.shape[0] != b:
                 self._logits = torch.full((b, hip.ACTION_SPACE), float("-inf"), dtype=torch.float32, device=self.device)
@@ -87,7 +87,6 @@ class HipResNetEvaluator:
             logits[:, self.reach] = F.linear(p.view(b, 2880), self.fc_pr_w, self.fc_pr_b)
         else:
             logits = F.linear(p.view(b, 2880), self.fc_p_w, self.fc_p_b)
-        v = hip.bias_act_(rows @ self.w_v.t(), self.b_v)
         v = F.relu(F.linear(v.view(b, 360), self.fc_v1_w, self.fc_v1_b))
         value = torch.tanh(F.linear(v, self.fc_v2_w, self.fc_v2_b))
         return logits, value.view(-1)
