@@ -1,27 +1,43 @@
 #!/usr/bin/env python3
-"""bench.py -- MCTS simulations/s of the MI355X self-play path on BASELINE.json's headline configuration.
+"""bench.py -- MCTS simulations/s (+ measured self-play games/hour) of the MI355X self-play path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts N fresh children (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torchrun would) before anything has touched the GPU,
+waits for them and returns their exit status -- the reference fans its workers out by itself in the same way
+(training/parallel_selfplay.py:284-293, 337-388).  Under an external launcher (torchrun) each rank runs main() directly.
+A rank count that differs from --gpus is an error (non-zero exit), never a silently smaller run.
 
 A *step* = one pass of the hot path over one batch: every one of the G resident games advances by ONE network
-evaluation (k_select -> ResNet forward over [G,15,10,9] -> k_expand/backup).  Inputs (game state, trees, weights)
-are resident in HBM when the timed region starts.  Simulations are counted by the engine itself (leaf evaluations
-and terminal leaves; root evaluations are reported separately).
+evaluation (k_select -> ResNet forward over [G,15,10,9] -> k_expand/backup).  Inputs (game state, trees, weights) are
+resident in HBM when the timed region starts.  Simulations are counted by the engine itself (leaf evaluations and
+terminal leaves; root evaluations are reported separately).
 
-Workload at N=1: BASELINE.json configs[2] -- 8192 concurrent games, 800 sims/move, 256ch x 10blk ResNet, fp32,
-synthetic data (games from the opening + random opening plies, counter-generated weights).  Weak scaling: every
-rank runs its own 8192 games; no collective in the data path.
+Workload at any N: BASELINE.json configs[2] per GPU -- 8192 concurrent games, 800 sims/move, 256ch x 10blk ResNet,
+fp32, synthetic data (games from the opening + random opening plies, counter-generated weights).  Weak scaling: every
+rank runs its own 8192 games; no collective in the data path.  The same line also carries
+  * "peaked": the same measurement with peaked-policy weights (deep, narrow trees: SURVEY.md section 8d's second
+    synthetic variant), unless --no-peaked;
+  * "games_per_hour_measured": COMPLETE games under the reference's termination rules at BASELINE configs[1]
+    (1024 games, 400 sims/move, 128x6) played inside this run, unless --complete-games 0;
+  * "cpu_baseline" (N = 1, rank 0): the reference's mode-1 worker restated on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA = 157.3       # TFLOP/s, MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM = 8000.0           # GB/s
+
 
 # FLOPs per evaluated position (2*MAC), SURVEY.md section 8a row a17
 def net_flops(c, b):
@@ -31,7 +47,17 @@ def net_flops(c, b):
     return tower + heads, tower
 
 
-def main():
+def workload_label(a):
+    """BASELINE.json config this argument set is, derived from the arguments (never hard-coded)."""
+    key = (a.games, a.sims, a.channels, a.blocks)
+    names = {(1024, 400, 128, 6): "BASELINE configs[1]", (8192, 800, 256, 10): "BASELINE configs[2]",
+             (8192, 800, 256, 20): "per-GPU share of BASELINE configs[3]"}
+    base = names.get(key, "custom (not a BASELINE config)")
+    return "%s: %d concurrent games per GPU, %d sims/move, %dch x %dblk ResNet%s" % (
+        base, a.games, a.sims, a.channels, a.blocks, ", PEAKED policy weights (policy_gain 8)" if a.peaked else "")
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -40,44 +66,79 @@ def main():
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--evaluator", default="auto", choices=["auto", "torch", "nhwc", "hip"])
+    ap.add_argument("--evaluator", default="hip", choices=["hip", "torch", "nhwc"])
+    ap.add_argument("--peaked", action="store_true", help="headline measurement itself on peaked-policy weights")
+    ap.add_argument("--no-peaked", action="store_true", help="skip the second (peaked) measurement")
+    ap.add_argument("--complete-games", type=int, default=1024,
+                    help="games of the measured games/hour leg (BASELINE configs[1]; 0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--prewarm", type=int, default=-1,
-                    help="untimed steps with a zero-logit evaluator that bring the staggered slots to the steady-state "
-                         "mix of search depths before warm-up (-1: sims+64, 0: off)")
-    args = ap.parse_args()
+                    help="untimed network-free steps that bring the staggered slots to the steady-state mix of search "
+                         "depths before warm-up (-1: sims+64, 0: off)")
+    return ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # one rank per GPU; XQ_BENCH_BACKEND=gloo lets several ranks share a card to rehearse the N>1 path on a 1-GPU box
-    backend = os.environ.get("XQ_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+def launch_ranks(args) -> int:
+    """Parent of a self-launched N-rank run.  Touches no GPU API; children are fresh interpreters."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), XQ_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                                  # one rank failed: stop exactly the children we started
+                    q.terminate()
+    return rc
+
+
+class PseudoPolicy:
+    """Network-free evaluator of the untimed prewarm: logits = gain * (planes . R) with a fixed seeded R, value 0.
+    gain 0 -> uniform priors (shallow, wide trees); gain > 0 -> peaked priors (deep, narrow trees), so the slots reach the
+    tree shape the timed steps will keep, at a few ms per step."""
+
+    def __init__(self, games, device, gain):
+        import torch
+        self.gain = gain
+        self.value = torch.zeros(games, dtype=torch.float32, device=device)
+        if gain > 0:
+            g = torch.Generator(device="cpu").manual_seed(99)
+            self.r = (torch.randn(1350, 8100, generator=g) * gain).to(device)
         else:
-            dist.init_process_group(backend)
+            self.logits = torch.zeros((games, 8100), dtype=torch.float32, device=device)
 
+    def __call__(self, x):
+        if self.gain > 0:
+            return x.reshape(x.shape[0], 1350) @ self.r, self.value
+        return self.logits, self.value
+
+
+def measure(args, dev, rank, world, dist, backend, peaked):
+    """One timed region: prewarm -> W warm-up steps -> barrier+sync, K steps, barrier+sync.  Returns the per-rank dict."""
+    import torch
     from xiangqi_alphazero_amd import engine, evaluator, model, weights
 
     net = model.XiangqiNet(args.channels, args.blocks)
-    net.load_state_dict(weights.make_state_dict(args.channels, args.blocks))
+    net.load_state_dict(weights.make_state_dict(args.channels, args.blocks, policy_gain=8.0 if peaked else 1.0))
     ev, ev_name = evaluator.make_evaluator(net, dev, args.evaluator)
     cfg = engine.make_config(args.games, args.sims, max_game_length=400, random_opening_moves=8,
                              temperature_threshold=20, enable_resign=True, seed=args.seed, rank=rank,   # "full" preset
                              start_stagger=True)
     eng = engine.SelfPlayEngine(cfg, dev, evaluator=ev)
-
     ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(4 * args.steps)]
 
     def sync():
@@ -86,16 +147,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # steady state: slots start staggered over one move's worth of steps; a zero-logit evaluator
-    # (uniform priors, value 0 -- no network) advances them until every slot is somewhere inside a search.
     prewarm = args.sims + 64 if args.prewarm < 0 else args.prewarm
     if prewarm:
-        z_logits = torch.zeros((args.games, 8100), dtype=torch.float32, device=dev)
-        z_value = torch.zeros(args.games, dtype=torch.float32, device=dev)
+        pp = PseudoPolicy(args.games, dev, 1.2 if peaked else 0.0)
         for _ in range(prewarm):
-            eng.select()
-            eng.expand(z_logits, z_value, False)
+            lg, vl = pp(eng.select())
+            eng.expand(lg, vl, False)
         torch.cuda.synchronize(dev)
+        del pp
     for _ in range(args.warmup):
         eng.step()
     sync()
@@ -116,79 +175,199 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     s1 = eng.stats()
+    if hasattr(ev, "timing"):
+        ev.timing = False
+    n = args.steps
+    sel_ms = sum(ev_t[4 * k].elapsed_time(ev_t[4 * k + 1]) for k in range(n)) / n
+    nn_ms = sum(ev_t[4 * k + 1].elapsed_time(ev_t[4 * k + 2]) for k in range(n)) / n
+    exp_ms = sum(ev_t[4 * k + 2].elapsed_time(ev_t[4 * k + 3]) for k in range(n)) / n
+    d = {k: s1[k] - s0[k] for k in ("sims", "depth_sum", "children_scanned", "nodes_created", "leaf_evals", "root_evals",
+                                    "terminal_sims")}
+    roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
+    out = dict(elapsed=elapsed, sims=d["sims"], sel_ms=sel_ms, nn_ms=nn_ms, exp_ms=exp_ms, d=d, roof=roof, ev_name=ev_name,
+               prewarm=prewarm)
+    del eng, ev
+    torch.cuda.empty_cache()
+    return out
 
-    sel_ms = sum(ev_t[4 * k].elapsed_time(ev_t[4 * k + 1]) for k in range(args.steps)) / args.steps
-    nn_ms = sum(ev_t[4 * k + 1].elapsed_time(ev_t[4 * k + 2]) for k in range(args.steps)) / args.steps
-    exp_ms = sum(ev_t[4 * k + 2].elapsed_time(ev_t[4 * k + 3]) for k in range(args.steps)) / args.steps
 
-    sims = s1["sims"] - s0["sims"]
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    t_sims = torch.tensor([float(sims)], dtype=torch.float64, device=dev)
+def reduce_ranks(m, dev, world, dist, backend):
+    """-> (max elapsed over ranks, total sims, per-rank sims/s list)."""
+    import torch
+    if world == 1:
+        return m["elapsed"], float(m["sims"]), [m["sims"] / m["elapsed"]]
+    tdev = dev if backend == "nccl" else "cpu"
+    mine = torch.tensor([m["elapsed"], float(m["sims"])], dtype=torch.float64, device=tdev)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    parts = [p.cpu() for p in parts]
+    return max(float(p[0]) for p in parts), sum(float(p[1]) for p in parts), [float(p[1]) / float(p[0]) for p in parts]
+
+
+def tree_block(args, m):
+    d = m["d"]
+    sims = max(d["sims"], 1)
+    evals = max(d["leaf_evals"] + d["root_evals"], 1)
+    tree = {"mean_depth": round(d["depth_sum"] / sims, 3), "children_read_per_sim": round(d["children_scanned"] / sims, 2),
+            "children_created_per_eval": round(d["nodes_created"] / evals, 2), "root_evals": d["root_evals"],
+            "terminal_sims": d["terminal_sims"]}
+    # engine kernels against HBM: algorithmic bytes (DESIGN.md section 4) x units counted by the engine itself
+    sel_bytes = 16 * d["children_scanned"] + 6 * d["depth_sum"] + 4 * (d["depth_sum"] + d["sims"]) + 5400 * evals + 2 * d["nodes_created"]
+    exp_bytes = 32400 * evals + 24 * d["nodes_created"] + 24 * (d["depth_sum"] + d["leaf_evals"])
+    roof = {}
+    for name, nbytes, ms in (("k_select", sel_bytes, m["sel_ms"]), ("k_expand", exp_bytes, m["exp_ms"])):
+        gbs = nbytes / args.steps / (ms * 1e-3) / 1e9
+        roof[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4)}
+    return tree, roof
+
+
+def complete_games_leg(args, dev, rank, world, dist, backend):
+    """Self-play games/hour MEASURED on complete games inside this run: BASELINE configs[1] (1024 concurrent games per
+    GPU, 400 sims/move, 128x6), reference termination rules, games_target = games so the tail has idle slots (the figure
+    under-states a refilling engine).  Timed like the main region: barrier + sync on both sides, max over ranks."""
+    import numpy as np
+    import torch
+    from xiangqi_alphazero_amd import model, selfplay, weights
+
+    class Cfg:                                  # "full" preset of training/train.py:692-704
+        c_puct = 1.5; temperature_threshold = 20; max_game_length = 400; random_opening_moves = 8
+        enable_resign = True; resign_threshold = -0.9; resign_check_steps = 5; num_simulations = 400
+
+    net = model.XiangqiNet(128, 6)
+    net.load_state_dict(weights.make_state_dict(128, 6))
+    games = args.complete_games
+    torch.cuda.synchronize(dev)
     if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_sims, op=dist.ReduceOp.SUM)
-    elapsed_max, sims_all = float(t_el.item()), float(t_sims.item())
+        dist.barrier()
+    t0 = time.perf_counter()
+    samples, results, st, _ = selfplay.run_games(net, Cfg, games, dev, n_slots=min(games, 1024), seed=args.seed + 7, rank=rank,
+                                                 evaluator_kind=args.evaluator, poll_every=256)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    steps = np.array([int(r["steps"]) for r in results])
+    mine = [elapsed, float(len(results)), float(st["sims"]), float(steps.sum())]
+    if world > 1:
+        tdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor(mine, dtype=torch.float64, device=tdev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        parts = [p.cpu().tolist() for p in parts]
+    else:
+        parts = [mine]
+    wall = max(p[0] for p in parts)
+    n_games = sum(p[1] for p in parts)
+    return {"config": "BASELINE configs[1] per GPU: %d complete games, 1024 slots, 400 sims/move, 128x6" % games,
+            "games_finished": int(n_games), "wall_s": round(wall, 2), "games_per_hour": round(n_games * 3600.0 / wall, 1),
+            "simulations_per_s": round(sum(p[2] for p in parts) / wall, 1),
+            "mean_plies_per_game": round(sum(p[3] for p in parts) / max(n_games, 1), 2),
+            "rank0": {"plies_p10": int(np.percentile(steps, 10)), "plies_p90": int(np.percentile(steps, 90)),
+                      "red_wins": st["red_wins"], "black_wins": st["black_wins"], "draws": st["draws"], "samples": int(len(samples))}}
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))            # nothing below runs in the launcher process
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a run of a different size" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # one rank per GPU; XQ_BENCH_BACKEND=gloo lets several ranks share a card to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("XQ_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU over RCCL)" % (world, n_dev))
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+
+    m = measure(args, dev, rank, world, dist, backend, args.peaked)
+    elapsed_max, sims_all, per_rank = reduce_ranks(m, dev, world, dist, backend)
+    mp = None
+    if not args.peaked and not args.no_peaked:
+        mp = measure(args, dev, rank, world, dist, backend, True)
+        mp_el, mp_sims, mp_rank = reduce_ranks(mp, dev, world, dist, backend)
+    gph = complete_games_leg(args, dev, rank, world, dist, backend) if args.complete_games > 0 else None
 
     if rank == 0:
-        flops_eval, flops_tower = net_flops(args.channels, args.blocks)
-        roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
+        flops_eval, _ = net_flops(args.channels, args.blocks)
+        roof = m["roof"]
+        not_measured = []
         if roof is not None and args.games == 8192 and args.channels == 256:
             # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
             # WRITE_SIZE, separate runs of this same command): counters cannot be read from inside this process.
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-                fk = [v for k, v in pmc["FETCH_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
-                wk = [v for k, v in pmc["WRITE_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
-                roof["traffic"] = int((2 * fk + wk) * 1024)     # gfx950: FETCH_SIZE counts 16-B/lane reads at half
-                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
-            except Exception:
-                pass
+            for f in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
+                    fk = [v for k, v in pmc["FETCH_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
+                    wk = [v for k, v in pmc["WRITE_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
+                    roof["traffic"] = int((2 * fk + wk) * 1024)     # gfx950: FETCH_SIZE counts 16-B/lane reads at half
+                    roof["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; separate --pmc passes)" % f
+                    not_measured.append("roofline.traffic")
+                    break
+                except Exception:
+                    continue
         if roof is None:
-            achieved = flops_eval * args.games / (nn_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "ResNet forward (%s), whole-network FLOPs / event-timed forward" % ev_name,
-                    "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4),
-                    "traffic": None}
-        d_depth = s1["depth_sum"] - s0["depth_sum"]
-        d_scan = s1["children_scanned"] - s0["children_scanned"]
-        d_nodes = s1["nodes_created"] - s0["nodes_created"]
+            achieved = flops_eval * args.games / (m["nn_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "ResNet forward (%s), whole-network FLOPs / event-timed forward" % m["ev_name"],
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None}
+        tree, tree_roof = tree_block(args, m)
+        value = sims_all / elapsed_max
         out = {
             "metric": "MCTS simulations/sec (whole node) + self-play games/hour, 256ch x 10blk ResNet",
-            "value": round(sims_all / elapsed_max, 1), "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d concurrent games per GPU, %d sims/move, %dch x %dblk ResNet"
-                       % (args.games, args.sims, args.channels, args.blocks),
-                       "games_per_gpu": args.games, "sims_per_move": args.sims, "net": "%dx%d" % (args.channels, args.blocks),
-                       "evaluator": ev_name, "prewarm_steps": prewarm, "parallelism": "games sharded across ranks, no data-path collective"},
+            "config": {"workload": workload_label(args), "games_per_gpu": args.games, "sims_per_move": args.sims,
+                       "net": "%dx%d" % (args.channels, args.blocks), "evaluator": m["ev_name"], "prewarm_steps": m["prewarm"],
+                       "parallelism": "games sharded across ranks, no data-path collective"},
+            "ranks": {"launched_by": "bench.py" if os.environ.get("XQ_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
+                      "backend": backend if world > 1 else None, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                      "sims_per_s_min": round(min(per_rank), 1), "sims_per_s_max": round(max(per_rank), 1)},
             "roofline": roof,
-            "breakdown_ms": {"select": round(sel_ms, 3), "evaluate": round(nn_ms, 3), "expand_backup": round(exp_ms, 3)},
-            "tree": {"mean_depth": round(d_depth / max(sims, 1), 3), "children_read_per_sim": round(d_scan / max(sims, 1), 2),
-                     "children_created_per_eval": round(d_nodes / max(s1["leaf_evals"] + s1["root_evals"] - s0["leaf_evals"] - s0["root_evals"], 1), 2),
-                     "root_evals": s1["root_evals"] - s0["root_evals"], "terminal_sims": s1["terminal_sims"] - s0["terminal_sims"]},
-            "games_per_hour_derived": None,
+            "breakdown_ms": {"select": round(m["sel_ms"], 3), "evaluate": round(m["nn_ms"], 3), "expand_backup": round(m["exp_ms"], 3)},
+            "tree": tree, "tree_roofline": tree_roof,
         }
-        # engine kernels against HBM: algorithmic bytes x units counted by the engine itself
-        d_evals = s1["leaf_evals"] + s1["root_evals"] - s0["leaf_evals"] - s0["root_evals"]
-        d_leaf = s1["leaf_evals"] - s0["leaf_evals"]
-        sel_bytes = 16 * d_scan + 6 * d_depth + 4 * (d_depth + sims) + 5400 * d_evals + 2 * d_nodes
-        exp_bytes = 32400 * d_evals + 24 * d_nodes + 24 * (d_depth + d_leaf)
-        out["tree_roofline"] = {
-            "k_select": {"bound": "hbm", "achieved": round(sel_bytes / args.steps / (sel_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(sel_bytes / args.steps / (sel_ms * 1e-3) / 8e12, 4)},
-            "k_expand": {"bound": "hbm", "achieved": round(exp_bytes / args.steps / (exp_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(exp_bytes / args.steps / (exp_ms * 1e-3) / 8e12, 4)}}
-        # games/hour cannot be observed in a few steps at 800 sims/move (one ply of all games = 801 steps); derive it
-        # from the measured simulation rate with the reference's own game-length bound (<= 200 plies, game.py:595).
-        out["games_per_hour_derived"] = {"at_200_plies": round(out["value"] * 3600 / (args.sims * 200.0), 1),
-                                         "at_100_plies": round(out["value"] * 3600 / (args.sims * 100.0), 1)}
-        try:    # mean game length MEASURED by tools/measure_games_per_hour.py (1024 complete games, configs[1])
-            gp = json.load(open(os.path.join(ROOT, "profiles", "r01_games_per_hour_cfg1_1024x400_128x6.json")))
-            mp = gp["plies_per_game"]["mean"]
-            out["games_per_hour_derived"]["at_measured_mean_plies"] = round(out["value"] * 3600 / (args.sims * mp), 1)
-            out["games_per_hour_derived"]["measured_mean_plies"] = mp
-            out["games_per_hour_measured_configs1"] = {"games_per_hour": gp["games_per_hour"], "config": gp["config"]}
-        except Exception:
-            pass
+        if mp is not None:
+            ptree, ptree_roof = tree_block(args, mp)
+            out["peaked"] = {"workload": "same configuration, peaked-policy weights (weights.make_state_dict policy_gain 8; prewarm "
+                                         "under a peaked pseudo-policy): deep, narrow trees",
+                             "value": round(mp_sims / mp_el, 1), "unit": "simulations/s", "ms_per_step": round(1e3 * mp_el / args.steps, 3),
+                             "breakdown_ms": {"select": round(mp["sel_ms"], 3), "evaluate": round(mp["nn_ms"], 3),
+                                              "expand_backup": round(mp["exp_ms"], 3)},
+                             "tree": ptree, "tree_roofline": ptree_roof}
+        # games/hour: measured on complete games at configs[1] (above); at this line's own configuration no game can finish
+        # inside a bench run (one ply of all games = sims+1 steps), so that figure is DERIVED from the measured simulation
+        # rate and the game length measured in this same run.
+        if gph is not None:
+            out["games_per_hour_measured"] = gph
+            mpl = gph["mean_plies_per_game"]
+            out["games_per_hour_derived"] = {"at_measured_mean_plies": round(value * 3600 / (args.sims * mpl), 1),
+                                             "measured_mean_plies": mpl, "at_200_plies": round(value * 3600 / (args.sims * 200.0), 1)}
+        else:
+            out["games_per_hour_derived"] = {"at_200_plies": round(value * 3600 / (args.sims * 200.0), 1)}
+        not_measured.append("games_per_hour_derived")
+        out["not_measured_in_this_run"] = not_measured
         if args.cpu_seconds > 0 and world == 1:
             from oracle import cpu_baseline                      # the checker, timed beside the product path
             cb = cpu_baseline.run(args.channels, args.blocks, budget_s=args.cpu_seconds)
@@ -196,8 +375,9 @@ def main():
                                    "sample": "%d workers x one %d-simulation search from the opening, %dx%d fp32 batch-1 predict "
                                              "(%.1f ms), 1 thread each, %.1f s" % (cb["cores"], cb["sims_per_worker"], args.channels,
                                                                                  args.blocks, cb["predict_ms"], cb["seconds"])}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -20,6 +20,8 @@ Fixtures written (all small):
   arena_traces.json     reference AlphaZeroTrainer._serial_evaluate with stub models: per-game winner/steps, totals
   train_trace.json      reference AlphaZeroTrainer.train_network on a recorded game's augmented samples (fixed batch order)
   nn_golden.npz         reference XiangqiNet outputs for generator weights (xiangqi-alphazero_amd/weights.py)
+  nn_golden2.npz        the same for 256x20 and for peaked policies (policy_gain 8), plus the reference's priors over
+                        the ordered legal moves (MCTS._mask_and_normalize of predict)
 """
 import argparse
 import importlib.util
@@ -475,6 +477,67 @@ def gen_nn():
     np.savez_compressed(os.path.join(HERE, "nn_golden.npz"), **out)
 
 
+def gen_nn2():
+    """Round-2 NN fixture (nn_golden2.npz): the AlphaZero-scale 256x20 net of BASELINE configs[3], and *peaked* policy
+    sets (weights.make_state_dict(policy_gain=8): probabilities O(0.1), so an absolute 1e-5 is a meaningful bound),
+    with -- per state -- the reference's priors over the ORDERED legal moves (MCTS._mask_and_normalize of
+    net.predict, mcts.py:176-188): what the engine's expansion must reproduce on the real network."""
+    import torch
+    import model as ref_model  # reference
+
+    torch.set_num_threads(4)
+    W = _load_weights_mod()
+    corpus = np.load(os.path.join(HERE, "corpus.npz"))
+    pick = np.linspace(5, len(corpus["board"]) - 7, 16).astype(int)
+    pick = np.array([i for i in pick if corpus["moves_off"][i + 1] > corpus["moves_off"][i]])   # non-terminal boards
+    states, legal = [], []
+    for i in pick:
+        g = XiangqiGame()
+        g.board[:] = corpus["board"][i].reshape(10, 9)
+        g.current_player = int(corpus["side"][i])
+        states.append(g.get_state_for_nn())
+        acts = g.get_legal_actions()
+        assert list(acts) == list(corpus["moves_flat"][corpus["moves_off"][i]:corpus["moves_off"][i + 1]])
+        legal.append(list(acts))
+    states = np.stack(states)
+    sample_idx = (np.arange(512, dtype=np.int64) * 6151 + 29) % 8100
+    maxl = max(len(a) for a in legal)
+    out = dict(corpus_index=pick, sample_idx=sample_idx,
+               legal_count=np.array([len(a) for a in legal], dtype=np.int32))
+    la = np.zeros((len(legal), maxl), dtype=np.int32)
+    for i, a in enumerate(legal):
+        la[i, :len(a)] = a
+    out["legal_actions"] = la
+    for ch, nb, gain in ((256, 20, 1.0), (64, 3, 8.0), (128, 6, 8.0), (256, 10, 8.0), (256, 20, 8.0)):
+        net = ref_model.XiangqiNet(num_channels=ch, num_res_blocks=nb)
+        net.load_state_dict(W.make_state_dict(ch, nb, seed=0, policy_gain=gain))
+        net.eval()
+        probs, vals, priors = [], [], np.zeros((len(legal), maxl), dtype=np.float32)
+        for i, s in enumerate(states):
+            p, v = net.predict(s, "cpu")
+            probs.append(p); vals.append(v)
+            pr = ref_mcts.MCTS._mask_and_normalize(p, legal[i])
+            assert list(pr.keys()) == legal[i]
+            priors[i, :len(legal[i])] = np.array([pr[a] for a in legal[i]], dtype=np.float32)
+        probs = np.stack(probs)
+        with torch.no_grad():
+            logits, v2 = net(torch.from_numpy(states))
+        logits = logits.numpy()
+        tag = "%dx%d" % (ch, nb) + ("" if gain == 1.0 else "_pg%d" % int(gain))
+        top = np.argsort(-probs, axis=1)[:, :64]
+        out[tag + "_value"] = np.array(vals, dtype=np.float64)
+        out[tag + "_probs_sample"] = probs[:, sample_idx].astype(np.float32)
+        out[tag + "_top_idx"] = top.astype(np.int32)
+        out[tag + "_top_prob"] = np.take_along_axis(probs, top, axis=1).astype(np.float32)
+        out[tag + "_top_logit"] = np.take_along_axis(logits, top, axis=1).astype(np.float32)
+        out[tag + "_logits_sample"] = logits[:, sample_idx].astype(np.float32)
+        out[tag + "_logits_legal"] = np.stack([np.pad(logits[i, legal[i]], (0, maxl - len(legal[i]))) for i in range(len(legal))]).astype(np.float32)
+        out[tag + "_priors_legal"] = priors
+        print("nn2", tag, "values", np.round(vals[:4], 4), "max prob", probs.max(), "median top-1", np.median(probs.max(1)),
+              "max prior", priors.max())
+    np.savez_compressed(os.path.join(HERE, "nn_golden2.npz"), **out)
+
+
 def gen_arena():
     """Reference AlphaZeroTrainer._serial_evaluate (train.py:453-535) run unbound on a stand-in `self` whose two models
     are stub evaluators: per-game winner / steps are read from its own log lines, the totals from its return value."""
@@ -598,7 +661,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     steps = dict(perft=lambda: gen_perft(args.perft5), corpus=gen_corpus, crafted=gen_crafted,
-                 mcts=gen_mcts_traces, games=gen_game_traces, nn=gen_nn, arena=gen_arena, train=gen_train)
+                 mcts=gen_mcts_traces, games=gen_game_traces, nn=gen_nn, nn2=gen_nn2, arena=gen_arena, train=gen_train)
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

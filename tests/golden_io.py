@@ -60,6 +60,11 @@ def nn_golden():
     return {k: z[k] for k in z.files}
 
 
+def nn_golden2():
+    z = np.load(os.path.join(GOLDEN, "nn_golden2.npz"))
+    return {k: z[k] for k in z.files}
+
+
 def history_tail(d, i, n=12) -> np.ndarray:
     """Last n pre-move boards of the game position i belongs to (oldest first), int8[k,90], k<=n."""
     g, ply = d["game"][i], d["ply"][i]

@@ -1,0 +1,267 @@
+"""B2 parity of the hand-written evaluator AT THE SIZES THE BENCH NUMBERS ARE QUOTED ON (BASELINE configs[1..3]):
+  * every evaluator kernel (xq_stem_conv, xq_wino_conv3x3, xq_heads_1x1) at B = 8192, C = 256 and B = 1024, C = 128
+    against a float64 convolution / matmul of the same inputs computed on the device in chunks;
+  * the whole HipResNetEvaluator on 8192 planes that the ENGINE produced (xq_engine_select mid-search) against the
+    BN-folded network evaluated in float64 (and the library fp32 path beside it);
+  * the HIP tower's logits / probabilities / value against outputs recorded from the reference XiangqiNet
+    (tests/golden/nn_golden.npz, nn_golden2.npz: 64x3 ... 256x20, near-uniform and peaked policies);
+  * the edge the pruned policy row changes: a row whose largest logit sits in a column no piece can move along.
+Tolerances are written at each assertion; the contract is 1e-5 absolute on probabilities and value (north_star)."""
+import numpy as np
+import pytest
+
+import golden_io as G
+from oracle import xq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _f64_conv_nhwc(x, w, bias, chunk=256):
+    """float64 3x3 convolution of NHWC float32 x[B,90,C] with OIHW w, on the device, `chunk` boards at a time."""
+    import torch
+    import torch.nn.functional as F
+    b, _, c = x.shape
+    out = torch.empty((b, 90, w.shape[0]), dtype=torch.float64, device=x.device)
+    wd, bd = w.double(), bias.double()
+    for lo in range(0, b, chunk):
+        xc = x[lo:lo + chunk].view(-1, 10, 9, c).permute(0, 3, 1, 2).double()
+        out[lo:lo + chunk] = F.conv2d(xc, wd, bd, padding=1).permute(0, 2, 3, 1).reshape(-1, 90, w.shape[0])
+    return out
+
+
+@pytest.mark.parametrize("c,b", [(256, 8192), (128, 1024), (256, 8191), (64, 4097)])
+def test_winograd_conv_kernel_at_bench_sizes(c, b):
+    """k_wino_conv's block -> (tile group, channel slice) dealing, its 32-bit buffer offsets (B*90*C*4 up to 755 MB) and
+    the ragged last tile group, at the batch the headline is quoted on.  Bound as in test_nn_parity: 4e-5 on outputs of
+    standard deviation 1.4 (the kernel's own rounding; the network-level contract is checked below)."""
+    import torch
+    from xiangqi_alphazero_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(c + b)
+    x = torch.randn(b, 90, c, generator=g).cuda()
+    w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).cuda()
+    bias = (torch.randn(c, generator=g) * 0.1).cuda()
+    res = torch.randn(b, 90, c, generator=g).cuda()
+    u = hip.wino_transform_weights(w)
+    ref = _f64_conv_nhwc(x, w, bias)
+    for residual, relu in ((None, True), (res, True)):
+        out = torch.full_like(x, float("nan"))
+        hip.wino_conv3x3(x, u, bias, out, residual, relu)
+        torch.cuda.synchronize()
+        worst = 0.0
+        for lo in range(0, b, 1024):                     # float64 epilogue in chunks (memory)
+            want = ref[lo:lo + 1024] + (0 if residual is None else residual[lo:lo + 1024].double())
+            want = torch.relu(want) if relu else want
+            worst = max(worst, (out[lo:lo + 1024].double() - want).abs().max().item())
+        assert worst < 4e-5, (c, b, relu, worst)
+        assert not bool(torch.isnan(out).any())
+
+
+@pytest.mark.parametrize("c,games", [(256, 8192), (128, 1024)])
+def test_stem_and_heads_kernels_at_bench_sizes(c, games):
+    import torch
+    import torch.nn.functional as F
+    from xiangqi_alphazero_amd import hip
+    d = G.corpus()
+    g = torch.Generator(device="cpu").manual_seed(77 + c)
+    idx = torch.randint(0, len(d["board"]), (games,), generator=g).numpy()
+    tb = torch.from_numpy(d["board"][idx]).cuda()
+    ts = torch.from_numpy(d["side"][idx].astype(np.int8)).cuda()
+    planes = hip.encode(tb, ts)                                          # the encoder's planes, as the engine writes them
+    w = torch.randn(c, 15, 3, 3, generator=g) * 0.2
+    b = torch.randn(c, generator=g) * 0.1
+    out = torch.full((games, 90, c), float("nan"), device="cuda")
+    hip.stem_conv(planes, hip.stem_weights(w).cuda(), b.cuda(), out)
+    worst = 0.0
+    for lo in range(0, games, 1024):
+        want = torch.relu(F.conv2d(planes[lo:lo + 1024].double(), w.cuda().double(), b.cuda().double(), padding=1))
+        want = want.permute(0, 2, 3, 1).reshape(-1, 90, c)
+        worst = max(worst, (out[lo:lo + 1024].double() - want).abs().max().item())
+    assert worst < 5e-6, worst
+    # heads: 737 280 rows at games = 8192
+    rows = torch.relu(torch.randn(games * 90, c, generator=g)).cuda()
+    wh = (torch.randn(36, c, generator=g) * (2.0 / c) ** 0.5).cuda()
+    bh = (torch.randn(36, generator=g) * 0.1).cuda()
+    p, v = hip.heads_1x1(rows, wh, bh)
+    worst = 0.0
+    for lo in range(0, games * 90, 90 * 1024):
+        want = torch.relu(rows[lo:lo + 90 * 1024].double() @ wh.double().t() + bh.double())
+        worst = max(worst, (p[lo:lo + 90 * 1024].double() - want[:, :32]).abs().max().item(),
+                    (v[lo:lo + 90 * 1024].double() - want[:, 32:]).abs().max().item())
+    assert worst < 5e-6, worst
+
+
+def _f64_network(inf, x, chunk=256):
+    """The BN-folded network (model.InferenceNet, the fp32 reference restatement) evaluated in float64 on the device."""
+    import torch
+    import torch.nn.functional as F
+    dd = lambda t: t.cuda().double()
+    logits, values = [], []
+    for lo in range(0, x.shape[0], chunk):
+        h = F.relu(F.conv2d(x[lo:lo + chunk].double(), dd(inf.w_in), dd(inf.b_in), padding=1))
+        for i in range(inf.num_res_blocks):
+            y = F.relu(F.conv2d(h, dd(getattr(inf, f"w1_{i}")), dd(getattr(inf, f"b1_{i}")), padding=1))
+            y = F.conv2d(y, dd(getattr(inf, f"w2_{i}")), dd(getattr(inf, f"b2_{i}")), padding=1)
+            h = F.relu(y + h)
+        p = F.relu(F.conv2d(h, dd(inf.w_p), dd(inf.b_p))).flatten(1)
+        logits.append(F.linear(p, dd(inf.fc_p_w), dd(inf.fc_p_b)))
+        v = F.relu(F.conv2d(h, dd(inf.w_v), dd(inf.b_v))).flatten(1)
+        v = F.relu(F.linear(v, dd(inf.fc_v1_w), dd(inf.fc_v1_b)))
+        values.append(torch.tanh(F.linear(v, dd(inf.fc_v2_w), dd(inf.fc_v2_b))).view(-1))
+    return torch.cat(logits), torch.cat(values)
+
+
+def _engine_planes(games, sims, prewarm):
+    """`games` positions as xq_engine_select hands them to the evaluator in the middle of self-play searches."""
+    import torch
+    from xiangqi_alphazero_amd import engine
+    cfg = engine.make_config(games, sims, random_opening_moves=8, seed=11, start_stagger=True)
+    eng = engine.SelfPlayEngine(cfg, "cuda")
+    z_logits = torch.zeros((games, 8100), dtype=torch.float32, device="cuda")
+    z_value = torch.zeros(games, dtype=torch.float32, device="cuda")
+    for _ in range(prewarm):
+        eng.select()
+        eng.expand(z_logits, z_value, False)
+    x = eng.select().clone()
+    torch.cuda.synchronize()
+    assert eng.stats()["overflow"] == 0
+    return x
+
+
+@pytest.mark.parametrize("ch,nb,games", [(256, 10, 8192), (128, 6, 1024)])
+def test_hip_evaluator_on_engine_planes_at_bench_batch(ch, nb, games):
+    """BASELINE configs[2] / configs[1]: the evaluator the bench times, on the batch the bench times, against the
+    float64 evaluation of the same folded weights: logits within 2e-5, value within 1e-5, softmax within 1e-5."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    x = _engine_planes(games, 48, 64)
+    assert int((x.view(games, -1).abs().sum(1) > 0).sum().item()) >= games * 0.99    # live slots wrote planes
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(weights.make_state_dict(ch, nb))
+    ev, name = evaluator.make_evaluator(net, "cuda", "hip")
+    assert name.startswith("hip")
+    logits, value = ev(x, full_policy=True)
+    logits, value = logits.clone(), value.clone()
+    want_l, want_v = _f64_network(model.InferenceNet(net), x)
+    err_l = (logits.double() - want_l).abs().max().item()
+    err_v = (value.double() - want_v).abs().max().item()
+    err_p = (torch.softmax(logits.double(), 1) - torch.softmax(want_l, 1)).abs().max().item()
+    assert err_l < 2e-5 and err_v < TOL and err_p < TOL, (err_l, err_v, err_p)
+    # the engine-facing call (pruned policy row) carries the same numbers in the columns it computes
+    from xiangqi_alphazero_amd.sample_format import reachable_actions
+    reach = torch.from_numpy(reachable_actions()).cuda()
+    pruned, v2 = ev(x)
+    assert torch.equal(v2, value)
+    assert (pruned[:, reach].double() - want_l[:, reach]).abs().max().item() < 2e-5
+    # the library fp32 path (MIOpen / hipBLASLt) on the same batch, for scale: it is no closer to float64
+    lib_l, lib_v = evaluator.BatchedEvaluator(net, "cuda", micro_batch=1024)(x)
+    print("max |logit - f64|: hip %.2e, library fp32 %.2e; value: hip %.2e, library %.2e"
+          % (err_l, (lib_l.double() - want_l).abs().max().item(), err_v, (lib_v.double() - want_v).abs().max().item()))
+
+
+def _golden_states(g):
+    d = G.corpus()
+    return np.stack([O.encode_state(d["board"][i], int(d["side"][i])) for i in g["corpus_index"]])
+
+
+GOLD1 = [("64x3", 64, 3, 1.0), ("128x6", 128, 6, 1.0), ("256x10", 256, 10, 1.0)]
+GOLD2 = [("256x20", 256, 20, 1.0), ("64x3_pg8", 64, 3, 8.0), ("128x6_pg8", 128, 6, 8.0), ("256x10_pg8", 256, 10, 8.0),
+         ("256x20_pg8", 256, 20, 8.0)]
+
+
+@pytest.mark.parametrize("tag,ch,nb,gain", GOLD1 + GOLD2)
+def test_hip_tower_logits_and_probs_vs_reference_golden(tag, ch, nb, gain):
+    """HIP tower vs the reference XiangqiNet's recorded outputs: LOGITS (2e-5 for the near-uniform generator weights;
+    for the peaked sets, whose logits reach +-60, 2e-5 relative to the row's largest |logit|), probabilities and value
+    1e-5 absolute.  Peaked sets: top probabilities are O(0.1-1), so 1e-5 is a tight bound there."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    g = G.nn_golden() if (tag, ch, nb, gain) in GOLD1 else G.nn_golden2()
+    states = _golden_states(g)
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(weights.make_state_dict(ch, nb, policy_gain=gain))
+    ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
+    logits, v = ev(torch.from_numpy(states).cuda(), full_policy=True)
+    logits = logits.cpu().numpy()
+    si = g["sample_idx"]
+    scale = np.maximum(1.0, np.abs(g[tag + "_logits_sample"]).max(axis=1, keepdims=True))
+    assert (np.abs(logits[:, si] - g[tag + "_logits_sample"]) / scale).max() < 2e-5
+    probs = torch.softmax(torch.from_numpy(logits), 1).numpy()
+    np.testing.assert_allclose(probs[:, si], g[tag + "_probs_sample"], rtol=0, atol=TOL)
+    top = g[tag + "_top_idx"]
+    np.testing.assert_allclose(np.take_along_axis(probs, top, axis=1), g[tag + "_top_prob"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(v.cpu().numpy().reshape(-1), g[tag + "_value"], rtol=0, atol=TOL)
+    if tag + "_top_logit" in g:
+        sc = np.maximum(1.0, np.abs(g[tag + "_top_logit"]).max(axis=1, keepdims=True))
+        assert (np.abs(np.take_along_axis(logits, top, axis=1) - g[tag + "_top_logit"]) / sc).max() < 2e-5
+
+
+def _search_priors(logits_rows, boards, sides, is_probs=False):
+    """Root priors the engine derives from the given policy rows (one search-only slot per position)."""
+    import torch
+    from xiangqi_alphazero_amd import engine
+    n = len(boards)
+    eng = engine.SelfPlayEngine(engine.make_config(n, 4, add_noise=False, manual_moves=True))
+    for s in range(n):
+        eng.set_position(s, boards[s], int(sides[s]))
+    eng.select()
+    eng.expand(logits_rows, torch.zeros(n, dtype=torch.float32, device="cuda"), is_probs)
+    return [eng.read_root(s) for s in range(n)]
+
+
+def test_unreachable_column_edge_of_the_pruned_policy_row():
+    """mcts.py:176-188 falls back to UNIFORM priors when every legal probability of the softmax over ALL 8100 logits is
+    zero -- which a huge logit in a column that is not a legal move causes by underflow.  The engine reproduces that when
+    it is handed the full logits row (xq_engine_expand, policy_is_probs = 0: what `.predict`-protocol evaluators and the
+    library evaluators deliver).  The product evaluator never computes columns no piece can move along (-inf there), so
+    on the same network output it yields the softmax over the legal moves instead -- the mathematically exact priors the
+    reference loses to float32 underflow.  The two differ only when a logit gap exceeds ~87; this test pins both."""
+    import torch
+    from xiangqi_alphazero_amd.sample_format import reachable_actions
+    g = O.Game()
+    legal = list(O.legal_actions(g.board.reshape(90), g.current_player))
+    reach = set(int(a) for a in reachable_actions())
+    unreachable = next(a for a in range(8100) if a not in reach)
+    rng = np.random.default_rng(3)
+    row = rng.normal(0, 1.5, 8100).astype(np.float32)
+    full = row.copy()
+    full[unreachable] = 200.0                                            # exp(l - 200) underflows for every legal l
+    pruned = np.full(8100, -np.inf, dtype=np.float32)
+    idx = np.array(sorted(reach))
+    pruned[idx] = row[idx]
+    rows = torch.from_numpy(np.stack([full, pruned, row])).cuda()
+    boards = [g.board] * 3
+    r_full, r_pruned, r_plain = _search_priors(rows, boards, [g.current_player] * 3)
+    n = len(legal)
+    assert list(r_full["actions"]) == legal and list(r_pruned["actions"]) == legal
+    # (1) full row with the spike: the reference's fallback, uniform float64 1/n (mcts.py:184-186)
+    sm = torch.softmax(torch.from_numpy(full), 0).numpy()
+    assert float(sum(sm[a] for a in legal)) == 0.0                       # what the reference's prob_sum would be
+    np.testing.assert_array_equal(r_full["prior"], np.full(n, 1.0 / n))
+    # (2) pruned row: softmax over the computed columns, renormalised over the legal moves == the spike-free row's priors
+    np.testing.assert_allclose(r_pruned["prior"], r_plain["prior"], rtol=0, atol=2e-7)
+    want = torch.softmax(torch.from_numpy(row[legal].astype(np.float64)), 0).numpy()
+    np.testing.assert_allclose(r_pruned["prior"], want, rtol=0, atol=TOL)
+    assert abs(float(np.sum(r_pruned["prior"])) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("tag,ch,nb,gain", GOLD2)
+def test_engine_priors_on_real_network_vs_reference(tag, ch, nb, gain):
+    """Evaluator -> xq_engine_expand on the golden positions: the priors the engine stores for the ordered legal moves
+    against MCTS._mask_and_normalize(net.predict(state), legal) recorded from the reference (mcts.py:176-188), 1e-5."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    g = G.nn_golden2()
+    d = G.corpus()
+    idx = g["corpus_index"]
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(weights.make_state_dict(ch, nb, policy_gain=gain))
+    ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
+    states = torch.from_numpy(_golden_states(g)).cuda()
+    logits, _ = ev(states)
+    roots = _search_priors(logits.clone(), [d["board"][i] for i in idx], [d["side"][i] for i in idx])
+    for k, r in enumerate(roots):
+        n = int(g["legal_count"][k])
+        assert list(r["actions"]) == list(g["legal_actions"][k, :n])
+        np.testing.assert_allclose(r["prior"], g[tag + "_priors_legal"][k, :n], rtol=0, atol=TOL)

@@ -48,6 +48,34 @@ def test_model_restatement_cpu(ch, nb):
     np.testing.assert_allclose(logits.numpy()[:, g["sample_idx"]], g[tag + "_logits_sample"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("tag,ch,nb,gain", [("256x20", 256, 20, 1.0), ("64x3_pg8", 64, 3, 8.0), ("128x6_pg8", 128, 6, 8.0)])
+def test_model_restatement_cpu_round2_fixture(tag, ch, nb, gain):
+    """nn_golden2.npz (256x20 and peaked policies): module outputs, and the priors over the ordered legal moves --
+    MCTS._mask_and_normalize (mcts.py:176-188: builtin sum of float32 in move order, float32 divide) restated in numpy."""
+    import torch
+    from xiangqi_alphazero_amd import model, weights
+    torch.set_num_threads(4)
+    g, d = G.nn_golden2(), G.corpus()
+    states = np.stack([O.encode_state(d["board"][i], int(d["side"][i])) for i in g["corpus_index"]])
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(weights.make_state_dict(ch, nb, policy_gain=gain))
+    net.eval()
+    pv = [net.predict(s, "cpu") for s in states]
+    probs = np.stack([p for p, _ in pv])
+    np.testing.assert_allclose(probs[:, g["sample_idx"]], g[tag + "_probs_sample"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(np.take_along_axis(probs, g[tag + "_top_idx"], axis=1), g[tag + "_top_prob"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(np.array([v for _, v in pv]), g[tag + "_value"], rtol=0, atol=TOL)
+    for k, i in enumerate(g["corpus_index"]):
+        n = int(g["legal_count"][k])
+        legal = g["legal_actions"][k, :n]
+        assert list(legal) == list(O.legal_actions(d["board"][i], int(d["side"][i])))
+        p = probs[k, legal].astype(np.float32)
+        tot = np.float32(0)
+        for x in p:
+            tot = np.float32(tot + x)
+        np.testing.assert_allclose(p / tot, g[tag + "_priors_legal"][k, :n], rtol=0, atol=2e-6)
+
+
 def test_weight_generator_is_stable():
     from xiangqi_alphazero_amd import weights
     import zlib

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Move-generation throughput: positions/s of xq_movegen_batch on the perft(4)
-frontier of the opening (3 290 240 positions), beside the CPU oracle and -- when oracle/_ref was built -- the
-reference's own Cython engine called through its Python API, on one host core each."""
+frontier of the opening (3 290 240 positions), beside the C oracle (oracle/xq_oracle.c through ctypes) on one host core.
+The reference's own Cython engine is timed in the BUILD container only (tools/calibrate_cpu_port.py); nothing derived
+from the reference runs on the GPU box from this tool."""
 import json
 import os
 import sys
@@ -48,15 +49,6 @@ def main():
     out = {"positions": n, "perft5": total_moves, "gpu_ms_per_launch": round(gpu_s * 1e3, 3),
            "gpu_positions_per_s": round(n / gpu_s), "gpu_ns_per_position": round(gpu_s / n * 1e9, 2),
            "oracle_c_us_per_position_1core_via_ctypes": round(cpu_s * 1e6, 2)}
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
-        import game_core
-        t0 = time.perf_counter()
-        for i in range(50000):
-            game_core.cy_generate_legal_moves(hb[i].reshape(10, 9), int(hs[i]))
-        out["reference_cython_us_per_position_1core"] = round((time.perf_counter() - t0) / 50000 * 1e6, 2)
-    except Exception as e:                              # oracle/_ref not built on this box
-        out["reference_cython_us_per_position_1core"] = None
     print(json.dumps(out))
 
 

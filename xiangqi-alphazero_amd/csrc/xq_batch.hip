@@ -36,9 +36,10 @@ __global__ __launch_bounds__(64 * WPW) void k_movegen(const int8_t *__restrict__
     const int cnt = wave_movegen(s_board, player, s_mgs[wv], s_outs[wv], &ovf);
     uint16_t *dst = moves + (size_t)i * XQ_MAXM;
     for (int j = lane; j < cnt; j += 64) dst[j] = s_outs[wv][j];
+    const bool chk = in_chk ? wave_in_check(s_board, player) : false;    // probes dealt to lanes, two ballots
     if (lane == 0) {
         counts[i] = (uint16_t)cnt;
-        if (in_chk) in_chk[i] = in_check(s_board, player) ? 1 : 0;
+        if (in_chk) in_chk[i] = chk ? 1 : 0;
         if (status) status[i] = (uint8_t)ovf;
     }
 }

@@ -745,16 +745,24 @@ __global__ void k_init(Dev E) {
     if (slot == 0) { E.cnt[0] = 0; E.cnt[1] = 0; *E.started = 0; }
 }
 
-__global__ void k_reduce_stats(Dev E, unsigned long long *out) {
-    // one block; thread t < ST_N sums column t (OR for the overflow word)
-    const int t = threadIdx.x;
-    if (t >= ST_N) return;
+// Column sums of the per-slot counters [G][ST_N] (OR for the overflow word): each 256-thread block sweeps slot rows
+// (8 rows x 32 columns per pass, 256 contiguous bytes per row), folds its eight partial rows through LDS and adds the
+// result to the zeroed output with one atomic per column.
+__global__ __launch_bounds__(256) void k_reduce_stats(Dev E, unsigned long long *out) {
+    __shared__ unsigned long long part[8][ST_N];
+    const int col = threadIdx.x & (ST_N - 1), row = threadIdx.x >> 5;
     unsigned long long acc = 0;
-    for (int s = 0; s < E.cfg.n_games; ++s) {
-        const unsigned long long v = E.stats[(size_t)s * ST_N + t];
-        acc = (t == ST_OVF) ? (acc | v) : (acc + v);
+    for (int s = blockIdx.x * 8 + row; s < E.cfg.n_games; s += gridDim.x * 8) {
+        const unsigned long long v = E.stats[(size_t)s * ST_N + col];
+        acc = (col == ST_OVF) ? (acc | v) : (acc + v);
     }
-    out[t] = acc;
+    part[row][col] = acc;
+    __syncthreads();
+    if (row == 0) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) acc = (col == ST_OVF) ? (acc | part[r][col]) : (acc + part[r][col]);
+        if (col == ST_OVF) atomicOr(&out[col], acc); else atomicAdd(&out[col], acc);
+    }
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -868,7 +876,10 @@ int xq_engine_stats_read(const xq_engine *eng, xq_engine_stats *host_out, void *
     const Dev d = make_dev(eng);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *sum = (unsigned long long *)eng->p[P_STATSUM];
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d, sum);
+    XQ_TRY(hipMemsetAsync(sum, 0, ST_N * sizeof(unsigned long long), s));
+    int blocks = (eng->cfg.n_games + 63) / 64;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_reduce_stats, dim3(blocks), dim3(256), 0, s, d, sum);
     int rc = launch_status();
     if (rc != XQ_OK) return rc;
     unsigned long long h[ST_N];

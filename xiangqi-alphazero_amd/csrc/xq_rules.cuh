@@ -159,6 +159,53 @@ __device__ __forceinline__ bool in_check(const int8_t *b, int player) {
     return is_attacked(b, none, k / 9, k % 9, -player);
 }
 
+// game_core.pyx:543-555 / 104-189 with the WAVE as the unit: the 47 probes of the reverse attack scan on the king's
+// square are dealt to lanes -- lanes 0..35 hold the squares of the four rays (9 steps each; one ballot of "occupied" gives
+// every ray's first and second piece: the first attacks as rook or king, the second as cannon), lanes 36..43 the eight
+// knight origins with their legs, lanes 44..46 the pawn origins -- and a second ballot says whether any probe hit.
+// Same boolean as in_check(); all 64 lanes must call it together.
+__device__ __forceinline__ bool wave_in_check(const int8_t *b, int player) {
+    const VMove none{-1, -1, 0};
+    const int k = find_king(b, none, player);
+    if (k < 0) return true;
+    const int kr = k / 9, kc = k % 9, by = -player;
+    const int lane = lane_id();
+    int p = 0;
+    if (lane < 36) {
+        const int d = lane / 9, s = lane - d * 9 + 1;
+        int dr, dc;
+        ortho(d, dr, dc);
+        const int r = kr + dr * s, c = kc + dc * s;
+        if ((unsigned)r < 10u && (unsigned)c < 9u) p = b[r * 9 + c];
+    }
+    const unsigned long long occ = __ballot(p != 0);
+    bool hit = false;
+    if (lane < 36) {
+        const int d = lane / 9, idx = lane - d * 9;
+        const unsigned ray = (unsigned)(occ >> (d * 9)) & 0x1FFu;
+        if (ray) {
+            const unsigned rest = ray & (ray - 1u);
+            if (idx == __builtin_ctz(ray)) hit = (p == 5 * by || p == by);
+            else if (rest && idx == __builtin_ctz(rest)) hit = (p == 6 * by);
+        }
+    } else if (lane < 44) {
+        int dr, dc, lr, lc;
+        knight(lane - 36, dr, dc, lr, lc);
+        const int nr = kr + dr, nc = kc + dc;
+        if ((unsigned)nr < 10u && (unsigned)nc < 9u && b[nr * 9 + nc] == 4 * by) {
+            const int br = (dr == 2 || dr == -2) ? nr - dr / 2 : nr;
+            const int bc = (dr == 2 || dr == -2) ? nc : nc - dc / 2;
+            hit = b[br * 9 + bc] == 0;
+        }
+    } else if (lane < 47) {
+        const int j = lane - 44;                  // 0: the square a pawn advances from; 1, 2: sideways (after the river)
+        const int pr = j == 0 ? kr - by : kr, pc = j == 0 ? kc : (j == 1 ? kc - 1 : kc + 1);
+        const bool side_ok = j == 0 || (by == 1 ? kr >= 5 : kr <= 4);
+        if (side_ok && (unsigned)pr < 10u && (unsigned)pc < 9u) hit = b[pr * 9 + pc] == 7 * by;
+    }
+    return __ballot(hit) != 0ull;
+}
+
 // game_core.pyx:209-252 -- legality of one pseudo-legal move, on the virtual board
 __device__ __forceinline__ bool move_legal(const int8_t *b, int from, int to, int player) {
     const VMove m{from, to, (int)b[from]};

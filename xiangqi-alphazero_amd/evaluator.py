@@ -51,20 +51,19 @@ class BatchedEvaluator:
         return probs, float(value.item())
 
 
-def make_evaluator(net: XiangqiNet, device, kind: str = "auto"):
-    """-> (callable evaluator for the engine, name).  'hip': hand-written MFMA conv tower (csrc/xq_conv.hip) when the
-    library exports it, policy logits only in the columns a piece can ever move along (-inf elsewhere, hip_net.py); 'torch': PyTorch-ROCm ops (MIOpen/hipBLASLt); 'auto' prefers 'hip'."""
-    from . import hip
+def make_evaluator(net: XiangqiNet, device, kind: str = "hip"):
+    """-> (callable evaluator for the engine, name).
+    'hip' (the product path; 'auto' is an alias): the hand-written kernels (csrc/xq_conv.hip, xq_nn.hip); raises
+    `hip.XqError` when the library or a kernel is missing -- it never changes backend behind the caller's back.
+    'nhwc' / 'torch': ROCm-library evaluators (MIOpen / hipBLASLt), kept for comparison numbers only; selected explicitly."""
     if kind in ("auto", "hip"):
-        try:
-            from .hip_net import HipResNetEvaluator
-            return HipResNetEvaluator(net, device, engine_policy=True), "hip-winograd-mfma-f32"
-        except (ImportError, hip.XqError):
-            if kind == "hip":
-                raise
-    if kind in ("auto", "nhwc"):
+        from .hip_net import HipResNetEvaluator
+        return HipResNetEvaluator(net, device, engine_policy=True), "hip-winograd-mfma-f32"
+    if kind == "nhwc":
         return ChannelsLastEvaluator(net, device), "rocm-igemm-nhwc-f32+hip-epilogue"
-    return BatchedEvaluator(net, device), "torch-rocm-f32"
+    if kind == "torch":
+        return BatchedEvaluator(net, device), "torch-rocm-f32"
+    raise ValueError("unknown evaluator kind %r" % (kind,))
 
 
 class ChannelsLastEvaluator:

@@ -113,12 +113,17 @@ class HipResNetEvaluator:
         direct = 2.0 * 90 * 9 * self.C * self.C * batch
         tiles = (batch * 15 + 31) // 32 * 32
         mfma = 20 * 2.0 * tiles * self.C * self.C
-        ach = direct / (avg * 1e-3) / 1e12
+        alg = direct / (avg * 1e-3) / 1e12
+        issued = mfma / (avg * 1e-3) / 1e12
+        # `achieved` / `frac`: the FLOPs the MFMA pipe really issues (Winograd: 300 instead of 810 multiplies per board and
+        # channel pair) against the fp32 MFMA peak -- a utilisation, <= 1.  The direct-convolution FLOPs this launch
+        # REPLACES (SURVEY.md section 8a row a17's figure) over the same time is `algorithmic_tflops`; its ratio to the
+        # peak says how far past a perfect direct implicit GEMM the kernel is, and is not a utilisation.
         return {"bound": "mfma", "kernel": "k_wino_conv (fused Winograd F(2x3,3x3) 3x3 conv, fp32 MFMA 32x32x2)",
-                "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+                "achieved": round(issued, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(issued / 157.3, 4), "traffic": None,
                 "launches_timed": len(ms), "avg_launch_ms": round(avg, 4),
-                "algorithmic_flops_per_launch": direct, "mfma_flops_per_launch": mfma,
-                "mfma_issue_rate_tflops": round(mfma / (avg * 1e-3) / 1e12, 2),
+                "mfma_flops_per_launch": mfma, "algorithmic_flops_per_launch": direct,
+                "algorithmic_tflops": round(alg, 2), "algorithmic_speedup_vs_direct": round(alg / 157.3, 4),
                 "share_of_evaluate_ms": round(avg * 2 * self.num_res_blocks / nn_ms, 4)}
 
     def predict(self, state: np.ndarray, device=None):
