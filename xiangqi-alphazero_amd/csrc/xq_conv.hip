@@ -42,6 +42,14 @@
 
 #pragma clang fp contract(off)
 
+// In-situ ablation builds (tests/microbench/wino_ablate.sh; never in the shipped library): bit 1 no weight loads in the
+// main loop, 2 no input transform (and no LDS reads of the raw input), 4 LDS reads kept but the transform's arithmetic
+// dropped, 8 no staging of the next chunks (global -> LDS), 16 no main-loop barriers, 32 no epilogue, 64 no MFMAs.
+// Results are wrong by construction; only the launch time is read.
+#ifndef XQ_ABL
+#define XQ_ABL 0
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     auto rowpair = [&](f32x4 d1, f32x4 d2) __attribute__((always_inline)) { return pk_fma4(d2, sgn, d1); };
 
     f32x4 a[5], ub[5];
+    auto loop_barrier = [&]() __attribute__((always_inline)) { if (!(XQ_ABL & 16)) __syncthreads(); };
     // weight fragment f of a chunk: (q, nt) = (QO[f >> 1], f & 1), processing order of the column frequencies 1,2,3,0,4
     auto load_frag = [&](int chunk, int f, int slot) __attribute__((always_inline)) {
         const int q = (f >> 1) == 0 ? 1 : (f >> 1) == 1 ? 2 : (f >> 1) == 2 ? 3 : (f >> 1) == 3 ? 0 : 4;
@@ -207,12 +216,17 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
             const int q = g == 0 ? 1 : g == 1 ? 2 : g == 2 ? 3 : g == 3 ? 0 : 4;
             const int col = g == 0 ? 1 : g == 1 ? 3 : g == 2 ? 2 : g == 3 ? 0 : 4;
             const int slot = f % 5;
-            if (nt == 0) { d1 = ld4(Xr + tb1 + XO + col * XSTRIDE); d2 = ld4(Xr + tb2 + XO + col * XSTRIDE); }
-            if (f == 6) a[3] = t;                                     // column frequency 3 retired with fragment 5
-            if (f == 8) a[0] = v0;
+            if (nt == 0 && !(XQ_ABL & 2)) { d1 = ld4(Xr + tb1 + XO + col * XSTRIDE); d2 = ld4(Xr + tb2 + XO + col * XSTRIDE); }
+            if (!(XQ_ABL & 6)) {
+                if (f == 6) a[3] = t;                                 // column frequency 3 retired with fragment 5
+                if (f == 8) a[0] = v0;
+            }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                if (FIRST && jj == 0) {
+                if (XQ_ABL & 64) {
+                    if (FIRST && jj == 0) for (int e = 0; e < 16; ++e) acc[q][nt][e] = 0.0f;
+                    asm volatile("" ::"v"(a[q][jj]), "v"(ub[slot][jj]));
+                } else if (FIRST && jj == 0) {
                     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], zero, 0, 0, 0);
                 } else {
@@ -221,14 +235,19 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
                 if (jj == 1) __builtin_amdgcn_sched_barrier(0);
             }
             // weights: fragment f+5 replaces this one (f < 5: later in this chunk, else the next chunk's f-5)
-            if (f < 5) load_frag(lchunk, f + 5, slot); else load_frag(nchunk_u, f - 5, slot);
-            if (nt == 1) {
+            if (!(XQ_ABL & 1)) { if (f < 5) load_frag(lchunk, f + 5, slot); else load_frag(nchunk_u, f - 5, slot); }
+            if (nt == 1 && (XQ_ABL & 4)) {                             // ablation: reads stay live, no arithmetic
+                asm volatile("" ::"v"(d1), "v"(d2));
+                if (g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
+            }
+            if (nt == 1 && (XQ_ABL & 2) && g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
+            if (nt == 1 && !(XQ_ABL & 6)) {
                 if (g == 0) w1 = rowpair(d1, d2);
                 if (g == 1) { w3 = rowpair(d1, d2); t = pk_sub4(w3, w1); e = pk_fma4(w1, two, w3); fm = pk_fms4(w1, two, w3); }
                 if (g == 2) { w2 = rowpair(d1, d2); a[1] = pk_add4(fm, w2); a[2] = pk_fms4(w2, three, e); }
                 if (g == 3) {
                     w0 = rowpair(d1, d2); v0 = pk_fma4(pk_sub4(w0, w2), two, t);
-                    if (stage >= 0) { store_x(stage); load_x(stage + 1); }
+                    if (stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
                 }
                 if (g == 4) { const f32x4 w4 = rowpair(d1, d2); a[4] = pk_fma4(t, mtwo, pk_sub4(w4, w2)); }
             }
@@ -259,14 +278,20 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     // ---- main loop: chunk c multiplies (a, fragments) of chunk c, transforms chunk c+1 out of buffer (c+1)&1,
     // stores chunk c+2 into buffer c&1 and fetches chunk c+3; one barrier per chunk
     chunk_body(1, 0, std::integral_constant<int, XRAW>{}, 2, std::true_type{});
-    __syncthreads();
+    loop_barrier();
     chunk_body(2, 1, std::integral_constant<int, 0>{}, 3, std::false_type{});
-    __syncthreads();
+    loop_barrier();
     for (int c = 2; c < NCH; c += 2) {
         chunk_body(c + 1, c, std::integral_constant<int, XRAW>{}, c + 2, std::false_type{});
-        __syncthreads();
+        loop_barrier();
         chunk_body(c + 2 < NCH ? c + 2 : c + 1, c + 1, std::integral_constant<int, 0>{}, c + 3, std::false_type{});
-        __syncthreads();
+        loop_barrier();
+    }
+    if (XQ_ABL & 32) {                                 // ablation: no epilogue (keep the accumulators observable)
+        float sacc = 0.0f;
+        for (int q = 0; q < 5; ++q) for (int n = 0; n < 2; ++n) for (int e = 0; e < 16; ++e) sacc += acc[q][n][e];
+        if (sacc == 1234.5f) Y[tid] = sacc;
+        return;
     }
 
     // ---- epilogue: Y = A_r^T M A_c, bias, residual, ReLU; one 32-channel half at a time through LDS --------------
