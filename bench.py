@@ -140,6 +140,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
                              start_stagger=True)
     eng = engine.SelfPlayEngine(cfg, dev, evaluator=ev)
     ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(4 * args.steps)]
+    sparse = hasattr(ev, "evaluate_legal")
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -168,9 +169,14 @@ def measure(args, dev, rank, world, dist, backend, peaked):
         e[0].record()
         x = eng.select()
         e[1].record()
-        logits, value = ev(x)
-        e[2].record()
-        eng.expand(logits, value, False)
+        if sparse:                                 # logits of the legal moves only (xq_policy_head_legal), no dense row
+            ll, value = ev.evaluate_legal(x, eng.req_moves, eng.req_counts)
+            e[2].record()
+            eng.expand_legal(ll, value)
+        else:
+            logits, value = ev(x)
+            e[2].record()
+            eng.expand(logits, value, False)
         e[3].record()
     sync()
     elapsed = time.perf_counter() - t0
@@ -185,7 +191,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
                                     "terminal_sims")}
     roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
     out = dict(elapsed=elapsed, sims=d["sims"], sel_ms=sel_ms, nn_ms=nn_ms, exp_ms=exp_ms, d=d, roof=roof, ev_name=ev_name,
-               prewarm=prewarm)
+               prewarm=prewarm, sparse=sparse)
     del eng, ev
     torch.cuda.empty_cache()
     return out
@@ -213,7 +219,8 @@ def tree_block(args, m):
             "terminal_sims": d["terminal_sims"]}
     # engine kernels against HBM: algorithmic bytes x units counted by the engine itself
     sel_bytes = 16 * d["children_scanned"] + 6 * d["depth_sum"] + 4 * (d["depth_sum"] + d["sims"]) + 5400 * evals + 2 * d["nodes_created"]
-    exp_bytes = 32400 * evals + 24 * d["nodes_created"] + 24 * (d["depth_sum"] + d["leaf_evals"])
+    # k_expand reads the legal moves' logits only (4 B each) under the sparse hand-off, the dense 32 400-B row otherwise
+    exp_bytes = ((4 * d["nodes_created"]) if m["sparse"] else 32400 * evals) + 24 * d["nodes_created"] + 24 * (d["depth_sum"] + d["leaf_evals"])
     roof = {}
     for name, nbytes, ms in (("k_select", sel_bytes, m["sel_ms"]), ("k_expand", exp_bytes, m["exp_ms"])):
         gbs = nbytes / args.steps / (ms * 1e-3) / 1e9
@@ -339,7 +346,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_label(args), "games_per_gpu": args.games, "sims_per_move": args.sims,
-                       "net": "%dx%d" % (args.channels, args.blocks), "evaluator": m["ev_name"], "prewarm_steps": m["prewarm"],
+                       "net": "%dx%d" % (args.channels, args.blocks), "evaluator": m["ev_name"], "policy_handoff": "legal-move logits [G,128]" if m["sparse"] else "dense logits [G,8100]",
+                       "prewarm_steps": m["prewarm"],
                        "parallelism": "games sharded across ranks, no data-path collective"},
             "ranks": {"launched_by": "bench.py" if os.environ.get("XQ_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
                       "backend": backend if world > 1 else None, "world_size_seen": dist.get_world_size() if world > 1 else 1,

@@ -169,6 +169,18 @@ int xq_engine_select(const xq_engine *eng, float *dev_nn_input /* [G][15][90] */
 int xq_engine_expand(const xq_engine *eng, const float *dev_policy, const float *dev_value,
                      int policy_is_probs, void *stream);
 
+/* Sparse hand-off between the engine and the evaluator (replaces the dense 8100-wide policy row of mcts.py:157-188).
+ * xq_engine_requests: after xq_engine_select, *dev_moves = uint16[G][XQ_MAXM] holds the ORDERED legal moves of the
+ * position each slot handed to the evaluator and *dev_counts = int32[G] their number (0: the slot asked for nothing this
+ * step).  Both point into the engine's workspace and stay valid for its lifetime.
+ * xq_engine_expand_legal: like xq_engine_expand, but dev_legal_logits[slot][m] is the network's logit of legal move m
+ * only.  Priors = softmax over the legal logits, summed sequentially in float32 in move order and divided -- the
+ * reference's softmax over all 8100 followed by mask-and-normalise (model.py:122, mcts.py:176-188), whose common factor
+ * exp(max_legal - max_all)/denominator cancels; identical up to float32 rounding unless the reference's float32 softmax
+ * underflows (a logit gap above ~87), where the reference degrades to denormal or uniform priors and this stays exact. */
+int xq_engine_requests(const xq_engine *eng, const uint16_t **dev_moves, const int32_t **dev_counts);
+int xq_engine_expand_legal(const xq_engine *eng, const float *dev_legal_logits, const float *dev_value, void *stream);
+
 /* Synchronises `stream`, copies the counters to host. */
 int xq_engine_stats_read(const xq_engine *eng, xq_engine_stats *host_out, void *stream);
 
@@ -176,6 +188,11 @@ int xq_engine_stats_read(const xq_engine *eng, xq_engine_stats *host_out, void *
  * up to max_results game results (xq_game_result) to host buffers and resets the rings. */
 int xq_engine_drain(const xq_engine *eng, void *host_samples, int max_samples, int *n_samples,
                     void *host_results, int max_results, int *n_results, void *stream);
+
+/* The same into DEVICE buffers (the samples stay on the GPU for the replay buffer / the RCCL all-gather; nothing crosses
+ * PCIe).  With both buffers NULL it only reports the pending counts and consumes nothing.  Synchronises. */
+int xq_engine_drain_device(const xq_engine *eng, void *dev_samples, int max_samples, int *n_samples,
+                           void *dev_results, int max_results, int *n_results, void *stream);
 
 /* Test / serving hooks (MCTS.search for a given position, mcts.py:94-155). Synchronise. */
 int xq_engine_set_position(const xq_engine *eng, int slot, const int8_t *host_board, int side, int move_count,
@@ -210,6 +227,22 @@ int xq_stem_conv(const float *dev_planes, const float *dev_wt, const float *dev_
  *   dev_bias : float32[36];  dev_p : float32[rows][32];  dev_v : float32[rows][4].  channels % 16 == 0, <= 1024. */
 int xq_heads_1x1(const float *dev_h, const float *dev_w, const float *dev_bias, float *dev_p, float *dev_v,
                  long long rows, int channels, void *stream);
+
+/* Policy head's Linear(2880, 8100) (model.py:64-71) evaluated ONLY at the ordered legal moves of each pending evaluation
+ * -- what mcts.py:176-188 keeps of the 8 100 logits:  dev_out[g][m] = dev_bias[a] + <dev_feat[g], dev_w[a]>,
+ * a = dev_moves[g][m], m < dev_counts[g] (counts <= 0: the game is skipped, its row is left untouched).
+ *   dev_feat : float32[games][2880], the policy features in NHWC order (position-major, 32 channels) as xq_heads_1x1 writes
+ *              them;  dev_w : float32[8100][2880] with the columns permuted to that order
+ *              (w[a][hw*32 + c] = policy_head.4.weight[a][c*90 + hw]);  dev_bias : float32[8100];
+ *   dev_moves : uint16[games][XQ_MAXM], dev_counts : int32[games] (xq_engine_requests);  dev_out : float32[games][XQ_MAXM]. */
+int xq_policy_head_legal(const float *dev_feat, const float *dev_w, const float *dev_bias, const uint16_t *dev_moves,
+                         const int32_t *dev_counts, int games, float *dev_out, void *stream);
+
+/* Value head's Linear(360,128) + ReLU + Linear(128,1) + tanh (model.py:73-85) over the value features float32[games][360]
+ * (NHWC order, xq_heads_1x1's dev_v):  dev_w1t : float32[360][128], w1t[hw*4 + c][j] = value_head.4.weight[j][c*90 + hw];
+ * dev_b1 float32[128]; dev_w2 float32[128] = value_head.6.weight[0]; dev_b2 float32[1];  dev_value : float32[games]. */
+int xq_value_head(const float *dev_vfeat, const float *dev_w1t, const float *dev_b1, const float *dev_w2,
+                  const float *dev_b2, int games, float *dev_value, void *stream);
 
 /* 3x3 convolution, stride 1, pad 1, C -> C channels (ResBlock.conv1/conv2 with BatchNorm folded, model.py:25-36)
  * as fused Winograd F(2x3,3x3) -- F(2,3) along the 10 rows, F(3,3) at the points 0, +-1, 2, inf along the 9 columns -- on

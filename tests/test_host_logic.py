@@ -108,6 +108,88 @@ def test_two_rank_gloo_broadcast_and_gather(tmp_path):
         assert open(tmp_path / ("ok%d" % r)).read() == "1 1"
 
 
+def _loop_rank_main(rank, world, port, tmp):
+    """AlphaZeroLoop's collectives and control flow over gloo on CPU tensors.  The three GPU stages are replaced by
+    deterministic stand-ins (the engine, the HIP batch kernel and the arena games need the GPU; tests/test_training.py
+    runs the real ones there): what is under test is the sharding, the device-record all-gather into every rank's replay
+    buffer, rank-0 training + weight broadcast, the sharded arena table + broadcast verdict, and the final checkpoint."""
+    import types
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xiangqi_alphazero_amd import arena, train_loop, training
+    from xiangqi_alphazero_amd.sample_format import RESULT_DTYPE, SAMPLE_DTYPE
+    cfg = types.SimpleNamespace(
+        num_channels=16, num_res_blocks=1, num_simulations=8, c_puct=1.5, temperature_threshold=10, num_games_per_iter=5,
+        max_game_length=30, random_opening_moves=2, enable_resign=False, resign_threshold=-0.9, resign_check_steps=5,
+        learning_rate=0.01, weight_decay=1e-4, lr_milestones=[50], lr_gamma=0.1, max_buffer_size=64, min_buffer_size=4,
+        num_epochs=1, batch_size=8, eval_games=7, eval_simulations=4, eval_win_rate=0.55, save_interval=5,
+        num_iterations=3, checkpoint_dir=os.path.join(tmp, "ck%d" % rank))
+
+    class Loop(train_loop.AlphaZeroLoop):
+        def _play_shard(self, n_games):                 # n_games games of 3 samples each, tagged with rank and iteration
+            smp = np.zeros(3 * n_games, dtype=SAMPLE_DTYPE)
+            smp["slot"] = self.rank; smp["game_seq"] = self.iteration; smp["ply"] = np.arange(3 * n_games)
+            res = np.zeros(n_games, dtype=RESULT_DTYPE)
+            res["slot"] = self.rank; res["winner"] = 1 - 2 * self.rank; res["steps"] = 10 + self.rank
+            return (torch.from_numpy(smp.view(np.uint8).reshape(-1, 640).copy()),
+                    torch.from_numpy(res.view(np.uint8).reshape(-1, 16).copy()))
+
+    def fake_train(model, optimizer, scheduler, buffer, config, **kw):   # only rank 0 is ever asked to train
+        assert dist.get_rank() == 0
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.add_(0.01 * len(buffer))
+        return {"policy_loss": 1.0, "value_loss": 0.5, "total_loss": 1.5, "learning_rate": 0.01}
+
+    played = []
+
+    def fake_play_arena(en, eo, n, sims, maxlen, c_puct, device, policy_is_probs=False, first_game=0):
+        played.append((first_game, n))
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        games = np.arange(first_game, first_game + n)
+        res["slot"] = np.arange(n)
+        res["winner"] = np.where(games % 2 == 0, 1, np.where(games % 3 == 0, 0, -1))   # new (red in even games) wins a lot
+        res["steps"] = 20 + games
+        return res
+
+    training.train_network = fake_train
+    arena.play_arena = fake_play_arena
+    arena.ev_mod.make_evaluator = lambda net, device, kind: (None, "fake")
+    loop = Loop(cfg, device="cpu", seed=3)
+    stats = loop.train()
+    sd_c = torch.cat([t.reshape(-1).double() for t in loop.current_model.state_dict().values()])
+    sd_b = torch.cat([t.reshape(-1).double() for t in loop.best_model.state_dict().values()])
+    import hashlib
+    digest = hashlib.sha256(sd_c.numpy().tobytes() + sd_b.numpy().tobytes() + loop.buffer.store.numpy().tobytes()).hexdigest()
+    ev = stats[1]["evaluation"]
+    shares = [3, 2]                                    # 5 games over 2 ranks
+    ok = (len(stats) == 3 and stats[0]["self_play"]["games"] == 5 and stats[0]["self_play"]["new_samples"] == 30
+          and loop.total_games == 15 and len(loop.buffer) == 2 * min(32, 45) and loop.buffer.count == 32
+          and (ev["new_wins"], ev["old_wins"], ev["draws"]) == (6, 0, 1) and ev["model_updated"]
+          and played == ([(0, 4)] if rank == 0 else [(4, 3)]))
+    ok = ok and stats[0]["self_play"]["red_wins"] == shares[0] and stats[0]["self_play"]["black_wins"] == shares[1]
+    ok = ok and (rank != 0 or (os.path.exists(os.path.join(cfg.checkpoint_dir, "checkpoint_iter3.pt"))
+                               and os.path.exists(os.path.join(cfg.checkpoint_dir, "best_model.pt"))))
+    open(os.path.join(tmp, "loop%d" % rank), "w").write("%d %s" % (int(bool(ok)), digest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_alphazero_loop(tmp_path):
+    """world_size 2 over gloo: three iterations; both ranks must end with identical weights (current and best) and an
+    identical replay buffer, and rank 0 must have written the final checkpoint (train.py:636-637)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_loop_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = [open(tmp_path / ("loop%d" % r)).read().split() for r in range(2)]
+    assert out[0][0] == "1" and out[1][0] == "1", out
+    assert out[0][1] == out[1][1]
+
+
 def test_parallel_self_play_signature_matches_reference():
     import inspect
     from xiangqi_alphazero_amd import selfplay

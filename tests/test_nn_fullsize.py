@@ -197,16 +197,20 @@ def test_hip_tower_logits_and_probs_vs_reference_golden(tag, ch, nb, gain):
         assert (np.abs(np.take_along_axis(logits, top, axis=1) - g[tag + "_top_logit"]) / sc).max() < 2e-5
 
 
-def _search_priors(logits_rows, boards, sides, is_probs=False):
-    """Root priors the engine derives from the given policy rows (one search-only slot per position)."""
+def _search_priors(logits_rows, boards, sides, is_probs=False, evaluator=None):
+    """Root priors the engine derives from the given policy rows -- or, with `evaluator`, from the evaluator in its own
+    protocol (engine.evaluate_and_expand: legal-move logits for the hand-written one) -- one search-only slot per position."""
     import torch
     from xiangqi_alphazero_amd import engine
     n = len(boards)
-    eng = engine.SelfPlayEngine(engine.make_config(n, 4, add_noise=False, manual_moves=True))
+    eng = engine.SelfPlayEngine(engine.make_config(n, 4, add_noise=False, manual_moves=True), evaluator=evaluator)
     for s in range(n):
         eng.set_position(s, boards[s], int(sides[s]))
-    eng.select()
-    eng.expand(logits_rows, torch.zeros(n, dtype=torch.float32, device="cuda"), is_probs)
+    x = eng.select()
+    if evaluator is not None:
+        eng.evaluate_and_expand(x)
+    else:
+        eng.expand(logits_rows, torch.zeros(n, dtype=torch.float32, device="cuda"), is_probs)
     return [eng.read_root(s) for s in range(n)]
 
 
@@ -260,8 +264,92 @@ def test_engine_priors_on_real_network_vs_reference(tag, ch, nb, gain):
     ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
     states = torch.from_numpy(_golden_states(g)).cuda()
     logits, _ = ev(states)
-    roots = _search_priors(logits.clone(), [d["board"][i] for i in idx], [d["side"][i] for i in idx])
-    for k, r in enumerate(roots):
+    boards, sides = [d["board"][i] for i in idx], [d["side"][i] for i in idx]
+    dense = _search_priors(logits.clone(), boards, sides)                 # dense (pruned) row -> xq_engine_expand
+    sparse = _search_priors(None, boards, sides, evaluator=ev)            # the product hand-off: xq_policy_head_legal ->
+    for k, (r, r2) in enumerate(zip(dense, sparse)):                      # xq_engine_expand_legal
         n = int(g["legal_count"][k])
-        assert list(r["actions"]) == list(g["legal_actions"][k, :n])
+        assert list(r["actions"]) == list(g["legal_actions"][k, :n]) == list(r2["actions"])
         np.testing.assert_allclose(r["prior"], g[tag + "_priors_legal"][k, :n], rtol=0, atol=TOL)
+        np.testing.assert_allclose(r2["prior"], g[tag + "_priors_legal"][k, :n], rtol=0, atol=TOL)
+        assert abs(float(np.sum(r2["prior"])) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("games", [8192, 37])
+def test_policy_head_legal_kernel(games):
+    """xq_policy_head_legal against a float64 gather + matmul: random features / weights, random DISTINCT action ids per
+    game, counts covering 0, 1, odd, 64/65 and the 128 cap; rows of games with count 0 must stay untouched."""
+    import torch
+    from xiangqi_alphazero_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(games)
+    feat = torch.relu(torch.randn(games, 2880, generator=g)).cuda()
+    w = (torch.randn(8100, 2880, generator=g) * 0.02).cuda()
+    bias = (torch.randn(8100, generator=g) * 0.1).cuda()
+    special = [0, 1, 2, 3, 41, 63, 64, 65, 127, 128]
+    counts = torch.randint(0, 70, (games,), generator=g).to(torch.int32)
+    counts[:len(special)] = torch.tensor(special[:games], dtype=torch.int32)
+    moves = torch.stack([torch.randperm(8100, generator=g)[:128] for _ in range(min(games, 64))])
+    moves = moves.repeat((games + 63) // 64, 1)[:games].contiguous()
+    moves = (moves + torch.arange(games).view(-1, 1) * 7) % 8100           # rows differ, ids stay distinct within a row
+    out = torch.full((games, 128), -7.0, device="cuda")
+    m16 = torch.from_numpy(moves.numpy().astype(np.uint16).view(np.int16)).cuda()
+    hip.policy_head_legal(feat, w, bias, m16, counts.cuda(), out)
+    torch.cuda.synchronize()
+    mc = moves.cuda()
+    worst = 0.0
+    for lo in range(0, games, 512):
+        wg = w[mc[lo:lo + 512]].double()                                  # [n,128,2880]
+        want = torch.einsum("gmk,gk->gm", wg, feat[lo:lo + 512].double()) + bias[mc[lo:lo + 512]].double()
+        valid = torch.arange(128, device="cuda").view(1, -1) < counts[lo:lo + 512].cuda().view(-1, 1)
+        got = out[lo:lo + 512].double()
+        worst = max(worst, ((got - want).abs() * valid).max().item())
+        assert bool((got[~valid] == -7.0).all())                          # nothing written past a game's count
+    assert worst < 2e-5, worst
+
+
+def test_value_head_kernel():
+    import torch
+    from xiangqi_alphazero_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(12)
+    for games in (1, 15, 16, 17, 8192):
+        vf = torch.relu(torch.randn(games, 360, generator=g)).cuda()
+        w1 = (torch.randn(128, 360, generator=g) * 0.08).cuda()
+        b1 = (torch.randn(128, generator=g) * 0.1).cuda()
+        w2 = (torch.randn(128, generator=g) * 0.1).cuda()
+        b2 = (torch.randn(1, generator=g) * 0.1).cuda()
+        got = hip.value_head(vf, w1.t().contiguous(), b1, w2, b2)
+        want = torch.tanh(torch.relu(vf.double() @ w1.double().t() + b1.double()) @ w2.double() + b2.double())
+        assert got.shape == (games,)
+        np.testing.assert_allclose(got.double().cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_evaluate_legal_matches_dense_logits_on_engine_requests():
+    """The product hand-off at the bench batch: for 8192 engine-produced requests, the legal-move logits of
+    xq_policy_head_legal equal the corresponding columns of the dense layer (same features, library GEMM) within 2e-5,
+    and slots that asked for nothing have count 0."""
+    import torch
+    from xiangqi_alphazero_amd import engine, evaluator, model, weights
+    games = 8192
+    net = model.XiangqiNet(64, 3)
+    net.load_state_dict(weights.make_state_dict(64, 3, policy_gain=4.0))
+    ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
+    cfg = engine.make_config(games, 32, random_opening_moves=8, seed=5, start_stagger=True)
+    eng = engine.SelfPlayEngine(cfg, "cuda", evaluator=ev)
+    for _ in range(40):
+        eng.step()
+    x = eng.select()
+    counts = eng.req_counts.clone()
+    moves = eng.req_moves.clone()
+    ll, value = ev.evaluate_legal(x, eng.req_moves, eng.req_counts)
+    full, value2 = ev(x, full_policy=True)
+    assert torch.equal(value, value2)
+    mv = (moves.to(torch.int32) & 0xFFFF).long()
+    valid = torch.arange(128, device="cuda").view(1, -1) < counts.view(-1, 1)
+    want = torch.gather(full, 1, mv.clamp(max=8099))
+    assert ((ll - want).abs() * valid).max().item() < 2e-5
+    phase = eng.slot_ints[:, 3]
+    waiting = (phase == 2) | (phase == 4)
+    assert bool((counts[~waiting] == 0).all()) and int(waiting.sum().item()) > games * 0.8
+    assert bool((counts[waiting & (phase == 4)] > 0).all())               # a leaf request always has legal moves
+    eng.expand_legal(ll, value)
+    assert eng.stats()["overflow"] == 0

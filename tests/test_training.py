@@ -157,3 +157,47 @@ def test_full_loop_two_iterations(tmp_path):
     same = all(torch.equal(a, b) for a, b in zip(loop.current_model.state_dict().values(), loop.best_model.state_dict().values()))
     assert same                                        # promoted or reverted: both leave current == best (train.py:525-533)
     assert ev["new_wins"] + ev["old_wins"] + ev["draws"] == 4
+
+
+def _loop_rank_gpu(rank, world, port, tmp):
+    import hashlib
+    import types
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xiangqi_alphazero_amd import train_loop
+    cfg = types.SimpleNamespace(
+        num_channels=64, num_res_blocks=1, num_simulations=8, c_puct=1.5, temperature_threshold=10, num_games_per_iter=12,
+        max_game_length=30, resign_threshold=-0.9, resign_check_steps=5, enable_resign=True, random_opening_moves=4,
+        num_iterations=2, batch_size=64, num_epochs=1, learning_rate=0.002, weight_decay=1e-4, lr_milestones=[50, 80],
+        lr_gamma=0.1, max_buffer_size=50000, min_buffer_size=100, eval_games=5, eval_win_rate=0.55, eval_simulations=8,
+        checkpoint_dir=os.path.join(tmp, "ck%d" % rank), save_interval=2)
+    loop = train_loop.AlphaZeroLoop(cfg, "cuda", seed=3)
+    stats = loop.train()
+    flat = torch.cat([t.reshape(-1).double() for t in list(loop.current_model.state_dict().values())
+                      + list(loop.best_model.state_dict().values())]).cpu().numpy()
+    digest = hashlib.sha256(flat.tobytes() + loop.buffer.store.cpu().numpy().tobytes()).hexdigest()
+    ev = stats[1]["evaluation"]
+    ok = (stats[0]["self_play"]["games"] == 12 and stats[0]["self_play"]["num_workers"] == 2 and len(loop.buffer) > 100
+          and stats[1]["self_play"]["buffer_size"] == len(loop.buffer) and ev["new_wins"] + ev["old_wins"] + ev["draws"] == 5
+          and (rank != 0 or stats[0]["training"]["policy_loss"] > 0))
+    open(os.path.join(tmp, "gloop%d" % rank), "w").write("%d %s %d" % (int(bool(ok)), digest, len(loop.buffer)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_full_loop_two_ranks_share_one_gpu(tmp_path):
+    """BASELINE configs[4]'s loop with world_size 2 (gloo; both ranks on the one GPU of the test box): games and arena
+    games sharded, device-resident samples all-gathered, rank-0 training + broadcast.  Both ranks must end with
+    bit-identical weights (current and best) and replay buffers."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_loop_rank_gpu, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = [open(tmp_path / ("gloop%d" % r)).read().split() for r in range(2)]
+    assert out[0][0] == "1" and out[1][0] == "1", out
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]

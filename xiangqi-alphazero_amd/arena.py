@@ -4,25 +4,53 @@ each), colours alternate by game index, every move is `MCTS.get_action(temperatu
 `eval_simulations`, a game still running after `max_game_length` plies is a draw, and
 `win_rate = (new_wins + 0.5 draws) / games >= eval_win_rate` promotes the candidate.  Deterministic (no random
 draws at all), so results are checked game by game against the reference's own arena under stub evaluators.
+
+Per step every slot is evaluated by ONE network -- the one whose side is searching (train.py:479-483) -- so a step costs
+one forward over the slots, split between the two models, not two.  With a process group the games are sharded over the
+ranks like self-play games (`distributed.shard_games`); the per-game results are all-gathered and every rank derives the
+same verdict from the same gathered table.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict
+from typing import Callable, Dict, Optional
 
+import numpy as np
 import torch
 
 from . import engine, evaluator as ev_mod
+from .sample_format import RESULT_DTYPE
+
+
+def _evaluate_subset(eng, ev, x, idx, policy_is_probs, dense, legal, value):
+    """Run `ev` on the slots `idx` (int64 device tensor) and scatter its outputs into the full-width buffers."""
+    if idx.numel() == 0:
+        return
+    xs = x.index_select(0, idx)
+    if hasattr(ev, "evaluate_legal") and not policy_is_probs:
+        ll, v = ev.evaluate_legal(xs, eng.req_moves.index_select(0, idx), eng.req_counts.index_select(0, idx))
+        legal.index_copy_(0, idx, ll)
+    else:
+        p, v = ev(xs)
+        dense.index_copy_(0, idx, p)
+    value.index_copy_(0, idx, v.view(-1))
 
 
 def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_simulations: int, max_game_length: int,
-               c_puct: float = 1.5, device="cuda", policy_is_probs: bool = False):
-    """eval_*: batched evaluators float32[G,15,10,9] -> (policy float32[G,8100], value float32[G]).
-    Returns the per-game results array (slot == game index; new model plays red in even games)."""
+               c_puct: float = 1.5, device="cuda", policy_is_probs: bool = False, first_game: int = 0):
+    """eval_*: evaluators in either protocol (`evaluate_legal`, or a callable float32[n,15,10,9] -> (policy
+    float32[n,8100], value float32[n])); both must use the same one.  Plays games first_game .. first_game+eval_games-1
+    of the arena (the new model is red in even games) and returns the results array ordered by game (slot == game -
+    first_game)."""
     cfg = engine.make_config(eval_games, eval_simulations, c_puct=c_puct, max_game_length=max_game_length,
                              random_opening_moves=0, enable_resign=False, add_noise=False, games_target=eval_games,
                              manual_moves=2)
     eng = engine.SelfPlayEngine(cfg, device)
-    new_is_red = (torch.arange(eval_games, device=eng.device) % 2 == 0)
+    dev = eng.device
+    new_is_red = ((torch.arange(eval_games, device=dev) + first_game) % 2 == 0)
+    sparse = hasattr(eval_new, "evaluate_legal") and hasattr(eval_old, "evaluate_legal") and not policy_is_probs
+    dense = None if sparse else torch.zeros((eval_games, 8100), dtype=torch.float32, device=dev)
+    legal = torch.zeros((eval_games, 128), dtype=torch.float32, device=dev) if sparse else None
+    value = torch.zeros(eval_games, dtype=torch.float32, device=dev)
     while True:
         for _ in range(64):
             x = eng.select()
@@ -30,11 +58,12 @@ def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_sim
             # choice follows the side to move of the real game, not of the evaluated position (train.py:479-483)
             red_to_move = eng.slot_ints[:, 0] == 1
             use_new = new_is_red == red_to_move
-            pn, vn = eval_new(x)
-            po, vo = eval_old(x)
-            policy = torch.where(use_new.unsqueeze(1), pn, po)
-            value = torch.where(use_new, vn.view(-1), vo.view(-1))
-            eng.expand(policy, value, policy_is_probs)
+            _evaluate_subset(eng, eval_new, x, use_new.nonzero().view(-1), policy_is_probs, dense, legal, value)
+            _evaluate_subset(eng, eval_old, x, (~use_new).nonzero().view(-1), policy_is_probs, dense, legal, value)
+            if sparse:
+                eng.expand_legal(legal, value)
+            else:
+                eng.expand(dense, value, policy_is_probs)
         st = eng.stats()
         if st["games_finished"] >= eval_games:
             break
@@ -42,22 +71,41 @@ def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_sim
     return results[results["slot"].argsort()]
 
 
-def evaluate_models(new_model, old_model, config, device="cuda", evaluator_kind: str = "auto") -> Dict[str, object]:
+def evaluate_models(new_model, old_model, config, device="cuda", evaluator_kind: str = "hip", group=None) -> Dict[str, object]:
     """Same stats dict as the reference (`new_wins, old_wins, draws, win_rate, model_updated`); reads
-    `eval_games, eval_simulations, c_puct, max_game_length, eval_win_rate` from `config` (train.py:97-100)."""
-    en, _ = ev_mod.make_evaluator(new_model, device, evaluator_kind)
-    eo, _ = ev_mod.make_evaluator(old_model, device, evaluator_kind)
-    res = play_arena(en, eo, int(config.eval_games), int(config.eval_simulations), int(config.max_game_length),
-                     float(config.c_puct), device)
+    `eval_games, eval_simulations, c_puct, max_game_length, eval_win_rate` from `config` (train.py:97-100).
+    Under torch.distributed the games are split over the ranks and the winners all-gathered."""
+    import torch.distributed as dist
+    from . import distributed as xdist
+    total = int(config.eval_games)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = xdist.shard_games(total, world, rank)
+    first = sum(xdist.shard_games(total, world, r) for r in range(rank))
+    winners = np.zeros(total, dtype=np.int64)
+    steps = np.zeros(total, dtype=np.int64)
+    if mine > 0:
+        en, _ = ev_mod.make_evaluator(new_model, device, evaluator_kind)
+        eo, _ = ev_mod.make_evaluator(old_model, device, evaluator_kind)
+        res = play_arena(en, eo, mine, int(config.eval_simulations), int(config.max_game_length), float(config.c_puct),
+                         device, first_game=first)
+        winners[first:first + mine] = res["winner"].astype(np.int64)
+        steps[first:first + mine] = res["steps"].astype(np.int64)
+    if world > 1:                     # disjoint shards: a sum gathers them; every rank ends with the same table
+        t = torch.from_numpy(np.stack([winners, steps])).to(device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, group=group)
+        winners, steps = t[0].cpu().numpy(), t[1].cpu().numpy()
     new_wins = old_wins = draws = 0
-    for r in res:
-        w, new_is_red = int(r["winner"]), int(r["slot"]) % 2 == 0
+    for game in range(total):
+        w, new_is_red = int(winners[game]), game % 2 == 0
         if w == 0:
             draws += 1
         elif (w == 1) == new_is_red:
             new_wins += 1
         else:
             old_wins += 1
-    win_rate = (new_wins + 0.5 * draws) / int(config.eval_games)
+    win_rate = (new_wins + 0.5 * draws) / total
+    games = np.zeros(total, dtype=RESULT_DTYPE)
+    games["slot"], games["winner"], games["steps"] = np.arange(total), winners, steps
     return {"new_wins": new_wins, "old_wins": old_wins, "draws": draws, "win_rate": win_rate,
-            "model_updated": win_rate >= float(config.eval_win_rate), "games": res}
+            "model_updated": win_rate >= float(config.eval_win_rate), "games": games}

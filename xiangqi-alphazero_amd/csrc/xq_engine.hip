@@ -42,7 +42,7 @@ enum St : int { ST_SIMS = 0, ST_TERM, ST_LEAF, ST_ROOT, ST_MOVES, ST_GAMES, ST_R
                 ST_DEPTH, ST_SCAN, ST_RESIGN, ST_SAMP, ST_DROP, ST_OVF, ST_STARTED, ST_N = 32 };
 
 enum Ptr : int { P_BOARD = 0, P_HIST, P_GI, P_RESIGN, P_PMOVES, P_PATH, P_TN, P_TW, P_TP, P_TA, P_TC, P_TM, P_ROOTP,
-                 P_STAGE, P_OUTS, P_OUTR, P_CNT, P_STATS, P_INJECT, P_SQRT, P_MNOISE, P_STATSUM };
+                 P_STAGE, P_OUTS, P_OUTR, P_CNT, P_STATS, P_INJECT, P_SQRT, P_MNOISE, P_STATSUM, P_REQ };
 
 enum Rng : int { RNG_RANDINT = 0, RNG_CHOICE = 1, RNG_DIRICHLET = 2, RNG_UNIFORM = 3 };
 
@@ -64,6 +64,7 @@ struct Dev {
     const uint64_t *inject;
     const double *sqrt_tab;
     double *mnoise;
+    int32_t *req;                   // [G] legal moves of the evaluation each slot asked for this step (0: none)
 };
 
 Dev make_dev(const xq_engine *e) {
@@ -78,7 +79,7 @@ Dev make_dev(const xq_engine *e) {
     d.outr = (uint8_t *)e->p[P_OUTR]; d.cnt = (unsigned int *)e->p[P_CNT];
     d.started = (unsigned long long *)((char *)e->p[P_CNT] + 16);
     d.stats = (unsigned long long *)e->p[P_STATS]; d.inject = (const uint64_t *)e->p[P_INJECT];
-    d.sqrt_tab = (const double *)e->p[P_SQRT]; d.mnoise = (double *)e->p[P_MNOISE];
+    d.sqrt_tab = (const double *)e->p[P_SQRT]; d.mnoise = (double *)e->p[P_MNOISE]; d.req = (int32_t *)e->p[P_REQ];
     return d;
 }
 
@@ -258,12 +259,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
     const bool arena = E.cfg.manual_moves == 2;      // evaluation games (train.py:453-535): T = 0, no opening, no samples
 
     int phase = __builtin_amdgcn_readfirstlane(gi[GI_PHASE]);
-    if (phase == PH_IDLE || phase == PH_HOLD || phase == PH_WAIT_ROOT || phase == PH_WAIT_LEAF) return;
+    if (phase == PH_WAIT_ROOT || phase == PH_WAIT_LEAF) return;        // still waiting: the request stands
+    if (phase == PH_IDLE || phase == PH_HOLD) { if (lane == 0) E.req[slot] = 0; return; }
     const int delay = __builtin_amdgcn_readfirstlane(gi[GI_DELAY]);
     if (delay > 0) {                                  // start_stagger: not started yet
-        if (lane == 0) gi[GI_DELAY] = delay - 1;
+        if (lane == 0) { gi[GI_DELAY] = delay - 1; E.req[slot] = 0; }
         return;
     }
+    int req_cnt = 0;
 
     int g_side = __builtin_amdgcn_readfirstlane(gi[GI_SIDE]);
     int g_mc = __builtin_amdgcn_readfirstlane(gi[GI_MC]);
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
                 tN[0] = 0; tW[0] = 0.0; tC[0] = -1; tM[0] = 0; tA[0] = 0; tP[0] = 0.0f;
             }
             sims_done = 0;
+            req_cnt = cnt;
             phase = PH_WAIT_ROOT;
             break;
         }
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
         wave_encode(L.board, side, nn_in + (size_t)slot * XQ_STATE_FLOATS);
         for (int j = lane; j < cnt; j += 64) pmoves[j] = L.moves[j];
         if (lane == 0) { gi[GI_PLEAF] = node; gi[GI_PDEPTH] = depth; gi[GI_PCOUNT] = cnt; }
+        req_cnt = cnt;
         phase = PH_WAIT_LEAF;
         break;
     }
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
         lds_copy_dwords(g_hist, L.rhist, XQ_HIST * XQ_BS / 4);
     }
     if (lane == 0) {
+        E.req[slot] = (phase == PH_WAIT_ROOT || phase == PH_WAIT_LEAF) ? req_cnt : 0;
         gi[GI_SIDE] = g_side; gi[GI_MC] = g_mc; gi[GI_NOCAP] = g_nocap; gi[GI_PHASE] = phase; gi[GI_SIMS] = sims_done;
         gi[GI_NSAMP] = n_samples; gi[GI_GSEQ] = game_seq;
         gi[GI_RNG0] = rng_ctr[0]; gi[GI_RNG1] = rng_ctr[1]; gi[GI_RNG2] = rng_ctr[2]; gi[GI_RNG3] = rng_ctr[3];
@@ -622,9 +628,18 @@ __global__ __launch_bounds__(64) void k_expand(Dev E, const float *__restrict__ 
     }
 
     // ---- priors of the legal moves: softmax over ALL 8100 logits (model.py:122), then mcts.py:176-188
-    const float *pol = policy + (size_t)slot * XQ_ACTION_SPACE;
+    // is_probs: 0 logits over all 8100 actions, 1 probabilities over all 8100, 2 logits of the legal moves only
+    // ([G][XQ_MAXM], move order): softmax over the legal logits -- the common factor of the full softmax cancels in
+    // mcts.py:176-188's renormalisation
+    const float *pol = policy + (size_t)slot * (is_probs == 2 ? XQ_MAXM : XQ_ACTION_SPACE);
     float mx = 0.0f, den = 1.0f;
-    if (!is_probs) {
+    if (is_probs == 2) {
+        float m = -INFINITY;
+        for (int i = lane; i < cnt; i += 64) m = fmaxf(m, pol[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        mx = m;
+    } else if (!is_probs) {
         const float4 *p4 = (const float4 *)pol;
         float m = -INFINITY;
         for (int i = lane; i < XQ_ACTION_SPACE / 4; i += 64) {
@@ -644,8 +659,8 @@ __global__ __launch_bounds__(64) void k_expand(Dev E, const float *__restrict__ 
     }
     for (int i = lane; i < cnt; i += 64) {
         const int a = pmoves[i];
-        const float x = pol[a];
-        L.p[i] = is_probs ? x : expf(x - mx) / den;
+        const float x = pol[is_probs == 2 ? i : a];
+        L.p[i] = is_probs == 1 ? x : expf(x - mx) / den;
         L.act[i] = (uint16_t)a;
     }
     wave_sync();
@@ -805,6 +820,7 @@ Layout make_layout(const xq_engine_config *c) {
     put(P_SQRT, (S + 2) * 8);
     put(P_MNOISE, G * XQ_MAXM * 8);
     put(P_STATSUM, ST_N * 8);
+    put(P_REQ, G * 4);
     l.total = o;
     return l;
 }
@@ -839,6 +855,7 @@ int xq_engine_init(xq_engine *eng, const xq_engine_config *cfg, void *ws, size_t
     XQ_TRY(hipMemsetAsync(eng->p[P_BOARD], 0, l.off[P_PATH] - l.off[P_BOARD], s));
     XQ_TRY(hipMemsetAsync(eng->p[P_ROOTP], 0, (size_t)cfg->n_games * XQ_MAXM * 8, s));
     XQ_TRY(hipMemsetAsync(eng->p[P_MNOISE], 0, (size_t)cfg->n_games * XQ_MAXM * 8, s));
+    XQ_TRY(hipMemsetAsync(eng->p[P_REQ], 0, (size_t)cfg->n_games * 4, s));
     {
         const int n = cfg->num_simulations + 2;
         double *tab = (double *)malloc(sizeof(double) * n);
@@ -867,7 +884,21 @@ int xq_engine_expand(const xq_engine *eng, const float *dev_policy, const float 
     if (!eng || !dev_policy || !dev_value) return XQ_ERR_ARG;
     const Dev d = make_dev(eng);
     hipLaunchKernelGGL(k_expand, dim3(eng->cfg.n_games), dim3(64), 0, (hipStream_t)stream, d, dev_policy, dev_value,
-                       policy_is_probs);
+                       policy_is_probs ? 1 : 0);
+    return launch_status();
+}
+
+int xq_engine_requests(const xq_engine *eng, const uint16_t **dev_moves, const int32_t **dev_counts) {
+    if (!eng || !dev_moves || !dev_counts) return XQ_ERR_ARG;
+    *dev_moves = (const uint16_t *)eng->p[P_PMOVES];
+    *dev_counts = (const int32_t *)eng->p[P_REQ];
+    return XQ_OK;
+}
+
+int xq_engine_expand_legal(const xq_engine *eng, const float *dev_legal_logits, const float *dev_value, void *stream) {
+    if (!eng || !dev_legal_logits || !dev_value) return XQ_ERR_ARG;
+    const Dev d = make_dev(eng);
+    hipLaunchKernelGGL(k_expand, dim3(eng->cfg.n_games), dim3(64), 0, (hipStream_t)stream, d, dev_legal_logits, dev_value, 2);
     return launch_status();
 }
 
@@ -912,6 +943,25 @@ int xq_engine_drain(const xq_engine *eng, void *host_samples, int max_samples, i
     if (nr && host_results) XQ_TRY(hipMemcpy(host_results, eng->p[P_OUTR], (size_t)nr * XQ_RESULT_BYTES, hipMemcpyDeviceToHost));
     XQ_TRY(hipMemset(eng->p[P_CNT], 0, 8));
     *n_samples = (int)ns; *n_results = (int)nr;
+    return XQ_OK;
+}
+
+int xq_engine_drain_device(const xq_engine *eng, void *dev_samples, int max_samples, int *n_samples, void *dev_results,
+                           int max_results, int *n_results, void *stream) {
+    if (!eng || !n_samples || !n_results) return XQ_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned cnt[2];
+    XQ_TRY(hipStreamSynchronize(s));
+    XQ_TRY(hipMemcpy(cnt, eng->p[P_CNT], sizeof(cnt), hipMemcpyDeviceToHost));
+    const unsigned ns = cnt[0] < (unsigned)eng->cfg.max_out_samples ? cnt[0] : (unsigned)eng->cfg.max_out_samples;
+    const unsigned nr = cnt[1] < (unsigned)eng->cfg.max_out_results ? cnt[1] : (unsigned)eng->cfg.max_out_results;
+    *n_samples = (int)ns; *n_results = (int)nr;
+    if (!dev_samples && !dev_results) return XQ_OK;          // size query: nothing is consumed
+    if ((int)ns > max_samples || (int)nr > max_results || (ns && !dev_samples) || (nr && !dev_results)) return XQ_ERR_ARG;
+    if (ns) XQ_TRY(hipMemcpyAsync(dev_samples, eng->p[P_OUTS], (size_t)ns * XQ_SAMPLE_BYTES, hipMemcpyDeviceToDevice, s));
+    if (nr) XQ_TRY(hipMemcpyAsync(dev_results, eng->p[P_OUTR], (size_t)nr * XQ_RESULT_BYTES, hipMemcpyDeviceToDevice, s));
+    XQ_TRY(hipMemsetAsync(eng->p[P_CNT], 0, 8, s));
+    XQ_TRY(hipStreamSynchronize(s));
     return XQ_OK;
 }
 

@@ -182,6 +182,98 @@ __global__ __launch_bounds__(256) void k_stem_conv(const float *__restrict__ X, 
     }
 }
 
+
+// Policy head's fully connected layer ONLY where the search needs it (model.py:64-71 Linear(2880, 8100) restricted to
+// the ordered legal moves of each pending evaluation, mcts.py:176-188): out[g][m] = b[a] + <feat[g], W[a]>, a = moves[g][m],
+// m < counts[g].  The reference computes all 8 100 logits per position (23.3 M multiply-adds) and keeps ~40; here a game
+// costs ~40 rows x 2 880 -- the dense [G, 8100] logits row (32 KB per position) never exists.  One wavefront per game:
+// the position's 2 880 features stay in registers (12 float4 per lane), each legal move streams its 11.5 KB weight row
+// (coalesced 1 KB per load instruction, served by L2 / Infinity Cache: the rows of the ~2 000 actions that occur are
+// re-read by many games), two rows in flight.  Bound by L2/MALL row traffic (games x legal x 11 520 B), not by FLOPs.
+constexpr int PF4 = 2880 / 4;             // float4 per feature / weight row
+__global__ __launch_bounds__(256) void k_policy_legal(const float *__restrict__ feat, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, const uint16_t *__restrict__ moves,
+                                                      const int32_t *__restrict__ counts, int games, float *__restrict__ out) {
+    const int g = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (g >= games) return;
+    const int lane = threadIdx.x & 63;
+    int cnt = counts[g];
+    cnt = cnt < 0 ? 0 : (cnt > XQ_MAXM ? XQ_MAXM : cnt);
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    if (cnt == 0) return;
+    const float4 *f4 = (const float4 *)(feat + (size_t)g * 2880);
+    float4 f[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) f[i] = (lane + 64 * i < PF4) ? f4[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint16_t *mv = moves + (size_t)g * XQ_MAXM;
+    float r0 = 0.0f, r1 = 0.0f;                        // results of moves lane and 64 + lane
+    auto row_dot = [&](int a) __attribute__((always_inline)) {
+        const float4 *w4 = (const float4 *)(W + (size_t)a * 2880);
+        float4 w[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w[i] = (lane + 64 * i < PF4) ? w4[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            s = fmaf(f[i].x, w[i].x, s); s = fmaf(f[i].y, w[i].y, s); s = fmaf(f[i].z, w[i].z, s); s = fmaf(f[i].w, w[i].w, s);
+        }
+        return s;
+    };
+    for (int m = 0; m < cnt; m += 2) {
+        const int a0 = __builtin_amdgcn_readfirstlane((int)mv[m]);
+        const int a1 = __builtin_amdgcn_readfirstlane((int)mv[m + 1 < cnt ? m + 1 : m]);
+        float s0 = row_dot(a0), s1 = row_dot(a1);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+        s0 += bias[a0]; s1 += bias[a1];
+        if (m < 64) { if (lane == m) r0 = s0; if (lane == m + 1) r0 = s1; }
+        else        { if (lane == m - 64) r1 = s0; if (lane == m - 63) r1 = s1; }
+    }
+    float *o = out + (size_t)g * XQ_MAXM;
+    if (lane < cnt) o[lane] = r0;
+    if (64 + lane < cnt) o[64 + lane] = r1;
+}
+
+// Value head's fully connected layers (model.py:73-85: Linear(360, 128) + ReLU + Linear(128, 1) + tanh) over the value
+// features float[G][90][4] that k_heads_1x1 wrote.  16 games per 128-thread block: the games' features sit in LDS,
+// thread j owns hidden unit j for all 16 games and streams its weight column (w1t[k][j]: coalesced, L2-resident 184 KB),
+// the 128 -> 1 layer is a wave reduction.  A 0.75 GFLOP problem at G = 8192: microseconds; it exists so that the
+// evaluator makes no library call.
+constexpr int VGB = 16;
+__global__ __launch_bounds__(128) void k_value_head(const float *__restrict__ vf, const float *__restrict__ w1t,
+                                                    const float *__restrict__ b1, const float *__restrict__ w2,
+                                                    const float *__restrict__ b2, int games, float *__restrict__ value) {
+    __shared__ __attribute__((aligned(16))) float vs[VGB][360];
+    __shared__ float part[2][VGB];
+    const int g0 = blockIdx.x * VGB, j = threadIdx.x;
+    for (int i = j; i < VGB * 360; i += 128) {
+        const int g = i / 360;
+        vs[g][i - g * 360] = g0 + g < games ? vf[(size_t)(g0 + g) * 360 + (i - g * 360)] : 0.0f;
+    }
+    __syncthreads();
+    float acc[VGB];
+#pragma unroll
+    for (int g = 0; g < VGB; ++g) acc[g] = 0.0f;
+    for (int k = 0; k < 360; k += 4) {
+        const float wa = w1t[(k + 0) * 128 + j], wb = w1t[(k + 1) * 128 + j], wc = w1t[(k + 2) * 128 + j], wd = w1t[(k + 3) * 128 + j];
+#pragma unroll
+        for (int g = 0; g < VGB; ++g) {
+            const float4 v = *(const float4 *)&vs[g][k];
+            acc[g] = fmaf(v.w, wd, fmaf(v.z, wc, fmaf(v.y, wb, fmaf(v.x, wa, acc[g]))));
+        }
+    }
+    const float bj = b1[j], wj = w2[j];
+#pragma unroll
+    for (int g = 0; g < VGB; ++g) {
+        float h = fmaxf(acc[g] + bj, 0.0f) * wj;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+        if ((j & 63) == 0) part[j >> 6][g] = h;
+    }
+    __syncthreads();
+    if (j < VGB && g0 + j < games) value[g0 + j] = tanhf(part[0][j] + part[1][j] + b2[0]);
+}
+
 }  // namespace
 
 extern "C" int xq_bias_act(float *dev_y, const float *dev_bias, const float *dev_residual, long long rows, int channels,
@@ -231,5 +323,24 @@ extern "C" int xq_stem_conv(const float *dev_planes, const float *dev_wt, const 
     if (((uintptr_t)dev_wt | (uintptr_t)dev_bias | (uintptr_t)dev_y) & 15) return XQ_ERR_ARG;
     if (games == 0) return XQ_OK;
     hipLaunchKernelGGL(k_stem_conv, dim3(games), dim3(256), 0, (hipStream_t)stream, dev_planes, dev_wt, dev_bias, dev_y, channels);
+    return xq::launch_status();
+}
+
+extern "C" int xq_policy_head_legal(const float *dev_feat, const float *dev_w, const float *dev_bias, const uint16_t *dev_moves,
+                                    const int32_t *dev_counts, int games, float *dev_out, void *stream) {
+    if (games < 0 || (games > 0 && (!dev_feat || !dev_w || !dev_bias || !dev_moves || !dev_counts || !dev_out))) return XQ_ERR_ARG;
+    if (((uintptr_t)dev_feat | (uintptr_t)dev_w) & 15) return XQ_ERR_ARG;
+    if (games == 0) return XQ_OK;
+    hipLaunchKernelGGL(k_policy_legal, dim3((games + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_feat, dev_w, dev_bias, dev_moves,
+                       dev_counts, games, dev_out);
+    return xq::launch_status();
+}
+
+extern "C" int xq_value_head(const float *dev_vfeat, const float *dev_w1t, const float *dev_b1, const float *dev_w2,
+                             const float *dev_b2, int games, float *dev_value, void *stream) {
+    if (games < 0 || (games > 0 && (!dev_vfeat || !dev_w1t || !dev_b1 || !dev_w2 || !dev_b2 || !dev_value))) return XQ_ERR_ARG;
+    if (games == 0) return XQ_OK;
+    hipLaunchKernelGGL(k_value_head, dim3((games + VGB - 1) / VGB), dim3(128), 0, (hipStream_t)stream, dev_vfeat, dev_w1t, dev_b1,
+                       dev_w2, dev_b2, games, dev_value);
     return xq::launch_status();
 }

@@ -67,3 +67,25 @@ def all_gather_samples(samples: np.ndarray, results: np.ndarray, device="cpu", g
     """Every rank ends up with every rank's finished samples and game results (rank order)."""
     return (_all_gather_records(samples, SAMPLE_DTYPE, torch.device(device), group),
             _all_gather_records(results, RESULT_DTYPE, torch.device(device), group))
+
+
+def all_gather_records_device(records: torch.Tensor, group=None) -> torch.Tensor:
+    """uint8[n_local, width] on any device (GPU under RCCL, CPU under gloo) -> uint8[sum n, width] on the same device, rank
+    order.  Counts are gathered first and every rank's block is padded to the largest (RCCL has no all-gatherv); the
+    records never leave the device -- this is what carries the engine's compact samples (xq_engine_drain_device) to the
+    trainer's device-resident replay buffer."""
+    world = dist.get_world_size(group)
+    dev = records.device
+    width = records.shape[1]
+    n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    most = max(counts)
+    if most == 0:
+        return records[:0]
+    buf = torch.zeros((most, width), dtype=torch.uint8, device=dev)
+    buf[:records.shape[0]] = records
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])

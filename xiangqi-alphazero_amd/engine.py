@@ -75,6 +75,12 @@ class SelfPlayEngine:
         # phase 3, simulations done 4): host-side policies such as the arena's model choice read it between stages
         gi_off = int(self.h.p[2]) - int(self.ws.data_ptr())
         self.slot_ints = self.ws[gi_off:gi_off + self.G * 32 * 4].view(torch.int32).view(self.G, 32)
+        # sparse hand-off to the evaluator (xq_engine_requests): ordered legal moves + their number per pending evaluation
+        pm, pc = C.c_void_p(), C.c_void_p()
+        hip.check(self.lib.xq_engine_requests(C.byref(self.h), C.byref(pm), C.byref(pc)), "xq_engine_requests")
+        mo, co = int(pm.value) - int(self.ws.data_ptr()), int(pc.value) - int(self.ws.data_ptr())
+        self.req_moves = self.ws[mo:mo + self.G * hip.MAXM * 2].view(torch.int16).view(self.G, hip.MAXM)
+        self.req_counts = self.ws[co:co + self.G * 4].view(torch.int32)
         self.steps = 0
 
     # ---- the three stages of a step --------------------------------------------------------------------
@@ -94,11 +100,33 @@ class SelfPlayEngine:
                                             hip.stream_ptr(self.device)), "xq_engine_expand")
         self._keep = (policy, value)   # keep alive until the stream has consumed them
 
+    def expand_legal(self, legal_logits: torch.Tensor, value: torch.Tensor):
+        """Expansion from the logits of the ORDERED LEGAL MOVES only (float32[G, 128], xq_engine_expand_legal)."""
+        if legal_logits.dtype != torch.float32 or value.dtype != torch.float32:
+            raise hip.XqError("legal_logits/value must be float32")
+        legal_logits = legal_logits.contiguous()
+        value = value.contiguous().view(-1)
+        if legal_logits.shape != (self.G, hip.MAXM) or value.shape != (self.G,):
+            raise hip.XqError(f"bad evaluator output shapes {tuple(legal_logits.shape)} {tuple(value.shape)}")
+        hip.check(self.lib.xq_engine_expand_legal(C.byref(self.h), legal_logits.data_ptr(), value.data_ptr(),
+                                                  hip.stream_ptr(self.device)), "xq_engine_expand_legal")
+        self._keep = (legal_logits, value)
+
+    def evaluate_and_expand(self, x: torch.Tensor, evaluator=None):
+        """Evaluator -> expansion in the evaluator's own protocol: one that offers `evaluate_legal(x, moves, counts)`
+        (the hand-written evaluator) is asked for the legal moves' logits only; any other callable returns the dense
+        [G, 8100] logits row of the reference protocol."""
+        ev = evaluator if evaluator is not None else self.evaluator
+        if hasattr(ev, "evaluate_legal"):
+            ll, value = ev.evaluate_legal(x, self.req_moves, self.req_counts)
+            self.expand_legal(ll, value)
+        else:
+            logits, value = ev(x)
+            self.expand(logits, value, False)
+
     def step(self):
         """select -> evaluator -> expand, all asynchronous on the current stream."""
-        x = self.select()
-        logits, value = self.evaluator(x)
-        self.expand(logits, value, False)
+        self.evaluate_and_expand(self.select())
         self.steps += 1
 
     # ---- bookkeeping --------------------------------------------------------------------------------------
@@ -117,6 +145,21 @@ class SelfPlayEngine:
         hip.check(self.lib.xq_engine_drain(C.byref(self.h), smp.ctypes.data, len(smp), C.byref(ns), res.ctypes.data,
                                            len(res), C.byref(nr), hip.stream_ptr(self.device)), "xq_engine_drain")
         return smp[:ns.value].copy(), res[:nr.value].copy()
+
+    def drain_device(self):
+        """-> (samples uint8[n, 640], results uint8[m, 16]) as DEVICE tensors (xq_engine_drain_device); empties the rings.
+        View them with `.cpu().numpy().view(SAMPLE_DTYPE / RESULT_DTYPE)` where host records are wanted."""
+        ns, nr = C.c_int(), C.c_int()
+        sp = hip.stream_ptr(self.device)
+        hip.check(self.lib.xq_engine_drain_device(C.byref(self.h), None, 0, C.byref(ns), None, 0, C.byref(nr), sp),
+                  "xq_engine_drain_device")
+        smp = torch.empty((ns.value, hip.SAMPLE_BYTES), dtype=torch.uint8, device=self.device)
+        res = torch.empty((nr.value, hip.RESULT_BYTES), dtype=torch.uint8, device=self.device)
+        if ns.value or nr.value:
+            hip.check(self.lib.xq_engine_drain_device(C.byref(self.h), smp.data_ptr() if ns.value else None, ns.value, C.byref(ns),
+                                                      res.data_ptr() if nr.value else None, nr.value, C.byref(nr), sp),
+                      "xq_engine_drain_device")
+        return smp, res
 
     def arena_views(self) -> dict:
         """Zero-copy torch views of the SoA tree arenas in the workspace, [G, node_cap] each:

@@ -91,6 +91,7 @@ def lib():
     L.xq_engine_expand.argtypes = [C.POINTER(Engine), vp, vp, i32, vp]
     L.xq_engine_stats_read.argtypes = [C.POINTER(Engine), C.POINTER(EngineStats), vp]
     L.xq_engine_drain.argtypes = [C.POINTER(Engine), vp, i32, C.POINTER(C.c_int), vp, i32, C.POINTER(C.c_int), vp]
+    L.xq_engine_drain_device.argtypes = [C.POINTER(Engine), vp, i32, C.POINTER(C.c_int), vp, i32, C.POINTER(C.c_int), vp]
     L.xq_engine_set_position.argtypes = [C.POINTER(Engine), i32, vp, i32, i32, i32, vp, vp, vp]
     L.xq_engine_read_root.argtypes = [C.POINTER(Engine), i32, vp, vp, vp, vp, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
@@ -101,6 +102,10 @@ def lib():
     L.xq_wino_weight_bytes.argtypes = [i32]
     L.xq_wino_weight_bytes.restype = C.c_size_t
     L.xq_wino_conv3x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.xq_policy_head_legal.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    L.xq_value_head.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    L.xq_engine_requests.argtypes = [C.POINTER(Engine), C.POINTER(vp), C.POINTER(vp)]
+    L.xq_engine_expand_legal.argtypes = [C.POINTER(Engine), vp, vp, vp]
     _lib = L
     return L
 
@@ -109,7 +114,8 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_encode_batch", "xq_material_batch", "xq_apply_moves_batch", "xq_game_over_batch",
            "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
            "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
-           "xq_bias_act", "xq_stem_conv", "xq_heads_1x1", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch"]
+           "xq_bias_act", "xq_stem_conv", "xq_heads_1x1", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch",
+           "xq_policy_head_legal", "xq_value_head", "xq_engine_requests", "xq_engine_expand_legal", "xq_engine_drain_device"]
 
 
 def check(rc: int, what: str):
@@ -277,3 +283,28 @@ def wino_conv3x3(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torc
                                 stream_ptr(x.device)), "xq_wino_conv3x3")
     return out
 
+
+
+def policy_head_legal(feat: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, moves: torch.Tensor, counts: torch.Tensor,
+                      out: torch.Tensor) -> torch.Tensor:
+    """feat float32[G, 2880] (NHWC policy features), w float32[8100, 2880] (columns in that order), bias float32[8100],
+    moves int16[G, 128] (uint16 action ids), counts int32[G] -> out float32[G, 128]: logits of the listed moves only."""
+    g = feat.shape[0]
+    if feat.shape != (g, 2880) or w.shape != (ACTION_SPACE, 2880) or moves.shape != (g, MAXM) or counts.shape != (g,) \
+            or out.shape != (g, MAXM) or counts.dtype != torch.int32 or moves.element_size() != 2 \
+            or not (feat.is_contiguous() and w.is_contiguous() and moves.is_contiguous() and counts.is_contiguous() and out.is_contiguous()):
+        raise XqError("policy_head_legal: feat [G,2880], w [8100,2880], moves 16-bit [G,128], counts int32 [G], out [G,128]")
+    check(lib().xq_policy_head_legal(feat.data_ptr(), w.data_ptr(), bias.data_ptr(), moves.data_ptr(), counts.data_ptr(), g,
+                                     out.data_ptr(), stream_ptr(feat.device)), "xq_policy_head_legal")
+    return out
+
+
+def value_head(vfeat: torch.Tensor, w1t: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """vfeat float32[G, 360] (NHWC value features), w1t float32[360, 128], b1 [128], w2 [128], b2 [1] -> value float32[G]."""
+    g = vfeat.shape[0]
+    if vfeat.shape != (g, 360) or w1t.shape != (360, 128) or not vfeat.is_contiguous() or not w1t.is_contiguous():
+        raise XqError("value_head: vfeat [G,360], w1t [360,128] contiguous required")
+    out = torch.empty(g, dtype=torch.float32, device=vfeat.device)
+    check(lib().xq_value_head(vfeat.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), g, out.data_ptr(),
+                              stream_ptr(vfeat.device)), "xq_value_head")
+    return out

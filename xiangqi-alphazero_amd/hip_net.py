@@ -2,13 +2,15 @@
 through `xq_wino_conv3x3` -- fused Winograd F(2x3,3x3) on the fp32 MFMA with folded-BN bias, ReLU and the skip
 connection in its epilogue -- on NHWC activations that ping-pong between preallocated buffers.  The 15->C input
 convolution reads the sparse encoder planes directly (`xq_stem_conv`), the heads' 1x1 convolutions are one pass over the
-tower output (`xq_heads_1x1`); only the heads' fully connected layers are ROCm library GEMMs.  fp32 throughout.
+tower output (`xq_heads_1x1`), the value head's two small fully connected layers are `xq_value_head`.  fp32 throughout.
 
-Engine-facing calls (`engine_policy=True`, what `evaluator.make_evaluator` builds) compute the policy head's 2880 -> 8100
-layer only for the 2 550 action ids some piece can ever move along (`sample_format.reachable_actions`) and leave -inf
-in the other columns: the softmax the engine takes over the row and renormalises over the legal moves
-(mcts.py:157-188) is unchanged, the GEMM is 3.2x smaller.  `predict()` -- the reference's single-position protocol, whose
-output is a distribution over all 8 100 ids -- always uses the full layer.
+Engine protocol (`evaluate_legal`, what `engine.evaluate_and_expand` calls): the policy head's 2880 -> 8100 layer is
+evaluated ONLY at the ordered legal moves of each pending evaluation (`xq_policy_head_legal`, ~40 of 8 100 rows per
+position) and handed to `xq_engine_expand_legal` as float32[G, 128]: the dense 32 KB/position logits row of the reference
+protocol (model.py:118-124, mcts.py:157-188) is never produced and no library GEMM runs.
+Dense protocol (`__call__`): logits over the 2 550 action ids some piece can ever move along (`reachable_actions`, -inf
+elsewhere; `engine_policy=True`) or over all 8 100 (`full_policy=True`, what `predict()` -- the reference's
+single-position protocol -- always uses); that one linear layer is a ROCm library GEMM through torch.
 """
 from __future__ import annotations
 
@@ -35,6 +37,7 @@ class HipResNetEvaluator:
         torch.backends.cudnn.allow_tf32 = False
         self._bufs = None
         self._logits = None          # engine_policy: persistent [B, 8100] rows, -inf outside the reachable columns
+        self._legal = None           # evaluate_legal: persistent [B, 128] legal-move logits
         self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []
@@ -59,18 +62,36 @@ class HipResNetEvaluator:
         self.fc_pr_w, self.fc_pr_b = dv(self.fc_p_w[self.reach]), dv(self.fc_p_b[self.reach])
         self.fc_v1_w, self.fc_v1_b = dv(fv), dv(ref.fc_v1_b)
         self.fc_v2_w, self.fc_v2_b = dv(ref.fc_v2_w), dv(ref.fc_v2_b)
+        self.fc_v1_wt = dv(fv.t())                                   # [360, 128] for xq_value_head
+        self.fc_v2_vec = dv(ref.fc_v2_w.reshape(-1))
 
     def _buffers(self, b):
-        if self._bufs is None or self._bufs[0].shape[0] != b:
+        """Four NHWC activation buffers, grown to the largest batch seen (callers with a varying batch -- the arena
+        evaluates only the searching side's slots -- get prefix views, no reallocation per step)."""
+        if self._bufs is None or self._bufs[0].shape[0] < b:
             self._bufs = [torch.empty((b, 90, self.C), dtype=torch.float32, device=self.device) for _ in range(4)]
-        return self._bufs
+        return [t[:b] for t in self._bufs]
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, full_policy: bool = False):
         F = torch.nn.functional
         b = x.shape[0]
+        p, v = self._tower(x)                                        # stem, residual tower, both heads' 1x1 convolutions
+        if self.engine_policy and not full_policy:
+            if self._logits is None or self._logits.shape[0] < b:
+                self._logits = torch.full((b, hip.ACTION_SPACE), float("-inf"), dtype=torch.float32, device=self.device)
+            logits = self._logits[:b]                                # consumed by xq_engine_expand before the next call
+            logits[:, self.reach] = F.linear(p.view(b, 2880), self.fc_pr_w, self.fc_pr_b)
+        else:
+            logits = F.linear(p.view(b, 2880), self.fc_p_w, self.fc_p_b)
+        value = hip.value_head(v.view(b, 360), self.fc_v1_wt, self.fc_v1_b, self.fc_v2_vec, self.fc_v2_b)
+        return logits, value
+
+    @torch.no_grad()
+    def _tower(self, x: torch.Tensor):
+        b = x.shape[0]
         t0, t1, t2, t3 = self._buffers(b)
-        h = hip.stem_conv(x.contiguous(), self.wt_in, self.b_in, t0)  # sparse input planes -> NHWC activations
+        h = hip.stem_conv(x.contiguous(), self.wt_in, self.b_in, t0)
         free = [t1, t2, t3]
         for u1, b1, u2, b2 in self.blocks:
             y = next(t for t in free if t.data_ptr() != h.data_ptr())
@@ -78,18 +99,21 @@ class HipResNetEvaluator:
             o = next(t for t in free if t.data_ptr() != h.data_ptr() and t.data_ptr() != y.data_ptr())
             self._conv(y, u2, b2, o, h)
             h = o
-        rows = h.view(b * 90, self.C)
-        p, v = hip.heads_1x1(rows, self.w_pv, self.b_pv)             # both 1x1 convolutions + bias + ReLU, one pass over h
-        if self.engine_policy and not full_policy:
-            if self._logits is None or self._logits.shape[0] != b:
-                self._logits = torch.full((b, hip.ACTION_SPACE), float("-inf"), dtype=torch.float32, device=self.device)
-            logits = self._logits                                    # consumed by xq_engine_expand before the next call
-            logits[:, self.reach] = F.linear(p.view(b, 2880), self.fc_pr_w, self.fc_pr_b)
-        else:
-            logits = F.linear(p.view(b, 2880), self.fc_p_w, self.fc_p_b)
-        v = F.relu(F.linear(v.view(b, 360), self.fc_v1_w, self.fc_v1_b))
-        value = torch.tanh(F.linear(v, self.fc_v2_w, self.fc_v2_b))
-        return logits, value.view(-1)
+        return hip.heads_1x1(h.view(b * 90, self.C), self.w_pv, self.b_pv)
+
+    @torch.no_grad()
+    def evaluate_legal(self, x: torch.Tensor, moves: torch.Tensor, counts: torch.Tensor):
+        """The engine's protocol (engine.evaluate_and_expand): logits of the ordered legal moves of every pending
+        evaluation, float32[G, 128], and the value float32[G] -- every kernel hand-written, no dense policy row.
+        Rows of slots that asked for nothing (count 0) are left as they were."""
+        b = x.shape[0]
+        p, v = self._tower(x)
+        if self._legal is None or self._legal.shape[0] < b:
+            self._legal = torch.zeros((b, hip.MAXM), dtype=torch.float32, device=self.device)
+        legal = self._legal[:b]
+        hip.policy_head_legal(p.view(b, 2880), self.fc_p_w, self.fc_p_b, moves, counts, legal)
+        value = hip.value_head(v.view(b, 360), self.fc_v1_wt, self.fc_v1_b, self.fc_v2_vec, self.fc_v2_b)
+        return legal, value
 
     def _conv(self, x, u, b, out, residual):
         if self.timing:

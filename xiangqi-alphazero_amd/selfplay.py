@@ -23,8 +23,9 @@ _CFG_KEYS = ("num_simulations", "c_puct", "temperature_threshold", "max_game_len
 
 
 def run_games(model, config, num_games: int, device="cuda", n_slots: Optional[int] = None, seed: int = 0, rank: int = 0,
-              evaluator_kind: str = "auto", poll_every: int = 64):
-    """Play `num_games` complete games; returns (samples, results, stats dict, elapsed seconds) in compact form."""
+              evaluator_kind: str = "hip", poll_every: int = 64, device_records: bool = False):
+    """Play `num_games` complete games; returns (samples, results, stats dict, elapsed seconds) in compact form:
+    structured numpy arrays, or -- `device_records` -- uint8 device tensors [n, 640] / [m, 16] that never left the GPU."""
     slots = int(n_slots or min(num_games, 8192))
     slots = max(1, min(slots, num_games))
     ev, ev_name = evaluator.make_evaluator(model, device, evaluator_kind)
@@ -43,7 +44,7 @@ def run_games(model, config, num_games: int, device="cuda", n_slots: Optional[in
         st = eng.stats()
         if st["games_finished"] >= num_games:
             break
-    samples, results = eng.drain()
+    samples, results = eng.drain_device() if device_records else eng.drain()
     st = eng.stats()
     st["evaluator"] = ev_name
     return samples, results, st, time.time() - t0

@@ -3,13 +3,17 @@ the engine underneath, one process per GPU (BASELINE configs[4]).
 
 Per iteration, exactly the reference's order:
   1. self-play     every rank plays `shard_games(num_games_per_iter, world, rank)` games on its own engine with the
-                   current best weights (no collective during search), then `all_gather_samples` brings every rank's
-                   compact records to every rank;
-  2. train         rank 0 runs `train_network` on its device-resident replay buffer; the new weights reach the other
-                   ranks as ONE flat `broadcast_weights`;
-  3. arena gate    every second iteration (train.py:609) the candidate plays the best model; promote at
-                   win_rate >= eval_win_rate, else the candidate reverts to the best weights (train.py:525-533);
-  4. checkpoint    every `save_interval` iterations, the reference's file format; `training_stats.json` like train.py:620-634.
+                   current best weights (no collective during search); the finished compact samples stay on the device
+                   (`xq_engine_drain_device`) and one padded all-gather of those device buffers brings every rank's
+                   records to every rank's device-resident replay buffer;
+  2. train         rank 0 runs `train_network` on its replay buffer; the new weights reach the other ranks as ONE flat
+                   `broadcast_weights`;
+  3. arena gate    every second iteration (train.py:609) the candidate plays the best model, the games sharded over the
+                   ranks (`arena.evaluate_models`); promote at win_rate >= eval_win_rate, else the candidate reverts to
+                   the best weights (train.py:525-533).  Every rank derives the verdict from the same all-reduced table
+                   and rank 0's decision is broadcast on top, so the replicas cannot drift apart;
+  4. checkpoint    every `save_interval` iterations and once more after the last one (train.py:613-615, 636-637), the
+                   reference's file format; `training_stats.json` like train.py:620-634.
 Works unchanged with world_size 1 (no process group needed).
 """
 from __future__ import annotations
@@ -20,15 +24,17 @@ import os
 import time
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import arena, distributed as xdist, selfplay, training
 from .model import XiangqiNet
+from .sample_format import RESULT_DTYPE
 
 
 class AlphaZeroLoop:
-    def __init__(self, config, device="cuda", seed: int = 0, evaluator_kind: str = "auto"):
+    def __init__(self, config, device="cuda", seed: int = 0, evaluator_kind: str = "hip"):
         self.config = config
         self.device = torch.device(device)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -48,27 +54,31 @@ class AlphaZeroLoop:
         self.training_stats = []
 
     # ---- the three stages --------------------------------------------------------------------------------
+    def _play_shard(self, n_games: int):
+        """-> (samples uint8[n,640], results uint8[m,16]) on self.device."""
+        if n_games <= 0:
+            return (torch.empty((0, 640), dtype=torch.uint8, device=self.device),
+                    torch.empty((0, 16), dtype=torch.uint8, device=self.device))
+        samples, results, _, _ = selfplay.run_games(self.best_model, self.config, n_games, self.device,
+                                                    seed=self.seed + 1000 * self.iteration, rank=self.rank,
+                                                    evaluator_kind=self.evaluator_kind, device_records=True)
+        return samples, results
+
     def self_play(self) -> dict:
         cfg = self.config
-        mine = xdist.shard_games(cfg.num_games_per_iter, self.world, self.rank)
         t0 = time.time()
-        if mine > 0:
-            samples, results, st, _ = selfplay.run_games(self.best_model, cfg, mine, self.device,
-                                                          seed=self.seed + 1000 * self.iteration, rank=self.rank,
-                                                          evaluator_kind=self.evaluator_kind)
-        else:
-            import numpy as np
-            from .sample_format import RESULT_DTYPE, SAMPLE_DTYPE
-            samples, results = np.zeros(0, SAMPLE_DTYPE), np.zeros(0, RESULT_DTYPE)
+        samples, results = self._play_shard(xdist.shard_games(cfg.num_games_per_iter, self.world, self.rank))
         if self.world > 1:
-            samples, results = xdist.all_gather_samples(samples, results, device=self.device)
+            samples = xdist.all_gather_records_device(samples)
+            results = xdist.all_gather_records_device(results)
         self.buffer.extend(samples)
-        self.total_games += len(results)
+        res = results.cpu().numpy().reshape(-1).view(RESULT_DTYPE) if len(results) else np.zeros(0, RESULT_DTYPE)
+        self.total_games += len(res)
         wins = {1: 0, -1: 0, 0: 0}
-        for r in results:
+        for r in res:
             wins[int(r["winner"])] += 1
-        return {"games": len(results), "red_wins": wins[1], "black_wins": wins[-1], "draws": wins[0],
-                "avg_steps": float(results["steps"].mean()) if len(results) else 0.0, "new_samples": 2 * len(samples),
+        return {"games": len(res), "red_wins": wins[1], "black_wins": wins[-1], "draws": wins[0],
+                "avg_steps": float(res["steps"].mean()) if len(res) else 0.0, "new_samples": 2 * int(samples.shape[0]),
                 "total_time": time.time() - t0, "num_workers": self.world, "mode": "hip", "buffer_size": len(self.buffer)}
 
     def train_network(self) -> dict:
@@ -79,14 +89,27 @@ class AlphaZeroLoop:
             xdist.broadcast_weights(self.current_model, src=0, device=self.device)
         return stats
 
+    def _arena(self) -> dict:
+        return arena.evaluate_models(self.current_model, self.best_model, self.config, self.device, self.evaluator_kind)
+
     def evaluate(self) -> dict:
-        stats = arena.evaluate_models(self.current_model, self.best_model, self.config, self.device, self.evaluator_kind)
+        stats = self._arena()
         stats.pop("games", None)
+        if self.world > 1:                             # one verdict for all replicas: rank 0's
+            flag = torch.tensor([1 if stats["model_updated"] else 0], dtype=torch.int64,
+                                device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            stats["model_updated"] = bool(flag.item())
         if stats["model_updated"]:
             self.best_model.load_state_dict(self.current_model.state_dict())
         else:
             self.current_model.load_state_dict(self.best_model.state_dict())
         return stats
+
+    def _save(self, iteration: int) -> None:
+        if self.rank == 0:
+            training.save_checkpoint(self.config.checkpoint_dir, iteration, self.current_model, self.best_model,
+                                     self.optimizer, self.scheduler, self.total_games, is_best=True)
 
     # ---- train.py:581-638 ------------------------------------------------------------------------------------
     def train(self, num_iterations: Optional[int] = None) -> list:
@@ -99,14 +122,15 @@ class AlphaZeroLoop:
             tr = self.train_network()
             ev = {}
             if iteration % 2 == 0 and len(self.buffer) >= cfg.min_buffer_size:
-                ev = self.evaluate()                   # deterministic: every rank reaches the same verdict
-            if iteration % cfg.save_interval == 0 and self.rank == 0:
-                training.save_checkpoint(cfg.checkpoint_dir, iteration, self.current_model, self.best_model,
-                                         self.optimizer, self.scheduler, self.total_games, is_best=True)
+                ev = self.evaluate()
+            if iteration % cfg.save_interval == 0:
+                self._save(iteration)
             self.training_stats.append({"iteration": iteration, "time": time.time() - t0, "self_play": sp,
                                         "training": tr, "evaluation": ev})
             if self.rank == 0:
                 os.makedirs(cfg.checkpoint_dir, exist_ok=True)
                 with open(os.path.join(cfg.checkpoint_dir, "training_stats.json"), "w") as f:
                     json.dump(self.training_stats, f, indent=2, default=str)
+        if self.iteration > 0:
+            self._save(self.iteration)                 # train.py:636-637: the final state is always on disk
         return self.training_stats

@@ -39,11 +39,15 @@ class ReplayBuffer:
     def __len__(self) -> int:
         return 2 * self.count
 
-    def extend(self, samples: np.ndarray) -> None:
-        """Append finished samples (structured array of SAMPLE_DTYPE, game order)."""
+    def extend(self, samples) -> None:
+        """Append finished samples, game order: a structured array of SAMPLE_DTYPE, or a uint8 tensor [n, 640] (device
+        records of `SelfPlayEngine.drain_device` / `all_gather_records_device`: no host hop)."""
         if len(samples) == 0:
             return
-        raw = torch.from_numpy(np.ascontiguousarray(samples).view(np.uint8).reshape(len(samples), hip.SAMPLE_BYTES))
+        if isinstance(samples, torch.Tensor):
+            raw = samples.view(-1, hip.SAMPLE_BYTES)
+        else:
+            raw = torch.from_numpy(np.ascontiguousarray(samples).view(np.uint8).reshape(len(samples), hip.SAMPLE_BYTES))
         raw = raw[-self.cap:].to(self.device)
         n = raw.shape[0]
         first = min(n, self.cap - self.head)
