@@ -325,7 +325,7 @@ def test_value_head_kernel():
 
 def test_evaluate_legal_matches_dense_logits_on_engine_requests():
     """The product hand-off at the bench batch: for 8192 engine-produced requests, the legal-move logits of
-    xq_policy_head_legal equal the corresponding columns of the dense layer (same features, library GEMM) within 2e-5,
+    xq_policy_head_legal equal the corresponding columns of the dense layer (same features, library GEMM) within 1e-5 of the logit scale,
     and slots that asked for nothing have count 0."""
     import torch
     from xiangqi_alphazero_amd import engine, evaluator, model, weights
@@ -346,7 +346,8 @@ def test_evaluate_legal_matches_dense_logits_on_engine_requests():
     mv = (moves.to(torch.int32) & 0xFFFF).long()
     valid = torch.arange(128, device="cuda").view(1, -1) < counts.view(-1, 1)
     want = torch.gather(full, 1, mv.clamp(max=8099))
-    assert ((ll - want).abs() * valid).max().item() < 2e-5
+    scale = max(1.0, float((want.abs() * valid).max().item()))          # two float32 evaluations of logits up to +-scale
+    assert ((ll - want).abs() * valid).max().item() < 1e-5 * scale
     phase = eng.slot_ints[:, 3]
     waiting = (phase == 2) | (phase == 4)
     assert bool((counts[~waiting] == 0).all()) and int(waiting.sum().item()) > games * 0.8

@@ -44,7 +44,9 @@
 
 // In-situ ablation builds (tests/microbench/wino_ablate.sh; never in the shipped library): bit 1 no weight loads in the
 // main loop, 2 no input transform (and no LDS reads of the raw input), 4 LDS reads kept but the transform's arithmetic
-// dropped, 8 no staging of the next chunks (global -> LDS), 16 no main-loop barriers, 32 no epilogue, 64 no MFMAs.
+// dropped, 8 no staging of the next chunks (global -> LDS), 16 no main-loop barriers, 32 no epilogue, 64 no MFMAs,
+// 128 staging loads from one contiguous run (coalesced), 256 staging loads from an L2-resident region, 512 staging issued
+// at the start of a chunk instead of its middle, 1024 weight loads always from chunk 0 (L1/L2-hot).
 // Results are wrong by construction; only the launch time is read.
 #ifndef XQ_ABL
 #define XQ_ABL 0
@@ -178,7 +180,14 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     f32x4 xreg[2];
     auto load_x = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) xreg[k] = buf_ld4(xrs, xgk[k], chunk * 32);
+        for (int k = 0; k < 2; ++k) {
+            if (XQ_ABL & 128)            // ablation: same bytes per chunk, but one contiguous 8 KB run per workgroup (coalesced)
+                xreg[k] = buf_ld4(xrs, (unsigned)b_lo * 90u * (unsigned)C * 4u + (unsigned)(tid + 256 * k) * 16u, chunk * 8192);
+            else if (XQ_ABL & 256)       // ablation: every workgroup reads the same 256 KB (L2-resident): latency without HBM
+                xreg[k] = buf_ld4(xrs, (unsigned)(tid + 256 * k) * 16u, chunk * 8192);
+            else
+                xreg[k] = buf_ld4(xrs, xgk[k], chunk * 32);
+        }
     };
     auto store_x = [&](int chunk) __attribute__((always_inline)) {
         char *dst = Xr + (chunk & 1) * XRAW;
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     // weight fragment f of a chunk: (q, nt) = (QO[f >> 1], f & 1), processing order of the column frequencies 1,2,3,0,4
     auto load_frag = [&](int chunk, int f, int slot) __attribute__((always_inline)) {
         const int q = (f >> 1) == 0 ? 1 : (f >> 1) == 1 ? 2 : (f >> 1) == 2 ? 3 : (f >> 1) == 3 ? 0 : 4;
-        ub[slot] = buf_ld4(urs, ul, (unsigned)chunk * UBUF_BYTES + q * (2 * NCO * 16) + (f & 1) * (32 * 16));
+        ub[slot] = buf_ld4(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f & 1) * (32 * 16));
     };
     auto transform0 = [&]() __attribute__((always_inline)) {
         f32x4 w[5];
@@ -242,12 +251,15 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
             }
             if (nt == 1 && (XQ_ABL & 2) && g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
             if (nt == 1 && !(XQ_ABL & 6)) {
-                if (g == 0) w1 = rowpair(d1, d2);
+                if (g == 0) {
+                    w1 = rowpair(d1, d2);
+                    if ((XQ_ABL & 512) && stage >= 0) { store_x(stage); load_x(stage + 1); }
+                }
                 if (g == 1) { w3 = rowpair(d1, d2); t = pk_sub4(w3, w1); e = pk_fma4(w1, two, w3); fm = pk_fms4(w1, two, w3); }
                 if (g == 2) { w2 = rowpair(d1, d2); a[1] = pk_add4(fm, w2); a[2] = pk_fms4(w2, three, e); }
                 if (g == 3) {
                     w0 = rowpair(d1, d2); v0 = pk_fma4(pk_sub4(w0, w2), two, t);
-                    if (stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
+                    if (stage >= 0 && !(XQ_ABL & (8 | 512))) { store_x(stage); load_x(stage + 1); }
                 }
                 if (g == 4) { const f32x4 w4 = rowpair(d1, d2); a[4] = pk_fma4(t, mtwo, pk_sub4(w4, w2)); }
             }
