@@ -256,7 +256,11 @@ int xq_value_head(const float *dev_vfeat, const float *dev_w1t, const float *dev
  *           xq_wino_weight_bytes(C) = 80 C^2 bytes.  channels in {64, 128, 256, 512}; batch*90*channels*4 < 2^32. */
 size_t xq_wino_weight_bytes(int channels);
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual,
-                    float *dev_y, int batch, int channels, int relu, void *stream);
+                    float *dev_y, int batch, int channels, int flags, void *stream);
+/* flags: bit 0 = ReLU; bit 1 = walk the batch back to front (same results; alternate it between consecutive layers so
+ * that each launch first reads what the previous one wrote last, while it is still in the Infinity Cache). */
+#define XQ_CONV_RELU 1
+#define XQ_CONV_REVERSE 2
 
 /* =====================================================================================
  * Next row (section 8f.1) -- training-batch materialisation.  Replaces SelfPlayDataset.__getitem__ + augment_data

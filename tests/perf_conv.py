@@ -1,7 +1,8 @@
 """Micro-benchmark of xq_wino_conv3x3 (not a test): python tests/perf_conv.py [B] [C]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xiangqi_alphazero_amd import hip
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

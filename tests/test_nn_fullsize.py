@@ -56,6 +56,9 @@ def test_winograd_conv_kernel_at_bench_sizes(c, b):
             worst = max(worst, (out[lo:lo + 1024].double() - want).abs().max().item())
         assert worst < 4e-5, (c, b, relu, worst)
         assert not bool(torch.isnan(out).any())
+        back = torch.full_like(x, float("nan"))                # XQ_CONV_REVERSE: same blocks, walked back to front
+        hip.wino_conv3x3(x, u, bias, back, residual, relu, reverse=True)
+        assert torch.equal(out, back)
 
 
 @pytest.mark.parametrize("c,games", [(256, 8192), (128, 1024)])

@@ -63,9 +63,19 @@ constexpr int NCO = 64;
 constexpr int KC = 8;
 constexpr int TILES = 32;                           // tiles per workgroup (2.13 boards)
 constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;      // one 8-channel chunk of weights for 64 output channels: 40 KB
-constexpr int XSTRIDE = 48;                          // bytes per staged position: 8 channels + 16 B pad
-constexpr int XPOS = (4 * 11 + 1) * 10 + 1;     // 4 boards with halo
-constexpr int XRAW = (XPOS + 1) * XSTRIDE;         // + one dump position
+// Staged raw input of one 8-channel chunk: two planes (channel quad h = 0, 1) of 16-byte units, one unit per halo'd
+// board position.  Unit of position (board b, halo'd row y' = y + 1 in 0..11, halo'd column x' = x + 1 in 0..10):
+//     b * XU_B + (y' >> 1) * XU_PAIR + (y' & 1) * XU_ODD + x'
+// Even and odd rows are split so that a tile's base unit b*XU_B + ty*XU_PAIR + 3 tx is == 3 * (global tile index) mod 16
+// (XU_PAIR == 9, XU_B == 13 mod 16): the 16 lanes that one ds_read_b128 services together -- 16 tiles with distinct
+// indices mod 16 -- then fall on 16 distinct bank quads, and every patch element is the base plus an immediate, so the
+// raw-input reads are bank-conflict free (the round-1 layout, 48-byte positions row-major, was 2.6-way conflicted).
+// The right halo of a row is the left halo of the row that follows it in memory (both zero).
+constexpr int XSTRIDE = 16;                          // bytes per unit
+constexpr int XU_ODD = 10, XU_PAIR = 25, XU_B = 157;
+constexpr int XPLANE = (4 * XU_B) * 16;             // 4 boards per plane
+constexpr int XDUMP = 4 * XU_B - 1;                 // a unit no tile reads: target of out-of-range staging lanes
+constexpr int XRAW = 2 * XPLANE;
 constexpr int ESTR = 36;                             // floats per tile row of an exchange plane (32 + 4: the two
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
@@ -124,7 +134,7 @@ __device__ __forceinline__ f32x4 pk_fms4(f32x4 x, f32x2 c, f32x4 y) {
 
 __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ X, const float *__restrict__ Ug,
                                                    const float *__restrict__ bias, const float *__restrict__ R,
-                                                   float *__restrict__ Y, int B, int C, int relu, int n_groups) {
+                                                   float *__restrict__ Y, int B, int C, int flags, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Xr = lds;
 
@@ -132,9 +142,14 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     const int NG = C / NCO;
     const int per = 8 / NG;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
-    const int cog = xcd % NG;
-    const int tg = rr * per + xcd / NG;
-    if (tg >= n_groups) return;
+    // ablation 2048 (C = 256): two weight slices per XCD, the two blocks that share a tile group back to back on it
+    const int cog = (XQ_ABL & 2048) ? 2 * (xcd & 1) + (rr & 1) : xcd % NG;
+    // flags bit 1: walk the batch back to front.  A launch that reads what the previous launch wrote (the next layer of
+    // the tower) then starts with the boards written last -- still in the 256 MB Infinity Cache -- instead of the oldest.
+    const int tg_fwd = (XQ_ABL & 2048) ? (rr >> 1) * 4 + (xcd >> 1) : rr * per + xcd / NG;
+    const int tg = (flags & 2) ? n_groups - 1 - tg_fwd : tg_fwd;
+    if (tg_fwd >= n_groups) return;
+    const int relu = flags & 1;
     const int T = B * 15;
     const int t0 = tg * TILES;
     const int b_lo = t0 / 15;
@@ -144,8 +159,9 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     // transform / MFMA role: tile l31, channel quad h, Winograd row wp
     const int gt = t0 + l31 < T ? t0 + l31 : T - 1;
     const int tb = gt / 15, tt = gt - tb * 15, ty = tt / 3, tx = tt - ty * 3;
-    const int tbase = (((tb - b_lo) * 11 + 2 * ty) * 10 + 3 * tx) * XSTRIDE + h * 16;       // P(tb, 2ty-1, 3tx-1)
-    const int tb1 = tbase + (wp == 0 ? 0 : 10) * XSTRIDE, tb2 = tbase + (wp == 3 ? 30 : 20) * XSTRIDE;
+    const int tbase = ((tb - b_lo) * XU_B + ty * XU_PAIR + 3 * tx) * XSTRIDE + h * XPLANE;   // P(tb, 2ty-1, 3tx-1)
+    const int tb1 = tbase + (wp == 0 ? 0 : XU_ODD) * XSTRIDE;                                 // patch row 0 or 1
+    const int tb2 = tbase + (wp == 3 ? XU_PAIR + XU_ODD : XU_PAIR) * XSTRIDE;                 // patch row 2 or 3
     const float sg = wp == 1 ? 1.0f : -1.0f;
     const f32x2 sgn = {sg, sg};
     const f32x2 two = {2.0f, 2.0f}, three = {3.0f, 3.0f}, mtwo = {-2.0f, -2.0f}, four = {4.0f, 4.0f};
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         const int bi = pos / 90, rem = pos - bi * 90, y = rem / 9, x = rem - y * 9;
         const bool ok = pos <= pos_last;
         xgk[k] = ok ? xgo + k * xstep : 0xFFFFFFF0u;
-        xl[k] = (ok ? (bi * 11 + y + 1) * 10 + x + 1 : XPOS) * XSTRIDE + spart * 16;
+        xl[k] = (ok ? bi * XU_B + ((y + 1) >> 1) * XU_PAIR + ((y + 1) & 1) * XU_ODD + x + 1 : XDUMP) * XSTRIDE + spart * XPLANE;
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((unsigned)B * 90u * (unsigned)C * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)(Ug + (size_t)cog * NCH * (UBUF_BYTES / 4)), 0,
@@ -384,7 +400,7 @@ extern "C" {
 size_t xq_wino_weight_bytes(int channels) { return (size_t)20 * channels * channels * sizeof(float); }
 
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual, float *dev_y,
-                      int batch, int channels, int relu, void *stream) {
+                      int batch, int channels, int flags, void *stream) {
     if (!dev_x || !dev_u || !dev_bias || !dev_y || batch <= 0) return XQ_ERR_ARG;
     if (channels < 64 || channels % 64 || 8 % (channels / 64)) return XQ_ERR_ARG;
     if (dev_x == dev_y || dev_residual == dev_y) return XQ_ERR_ARG;
@@ -399,7 +415,7 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     const int per = 8 / (channels / NCO);
     const int rows = (n_groups + per - 1) / per;
     hipLaunchKernelGGL(k_wino_conv, dim3(rows * 8), dim3(256), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
-                       dev_residual, dev_y, batch, channels, relu, n_groups);
+                       dev_residual, dev_y, batch, channels, flags, n_groups);
     return xq::launch_status();
 }
 

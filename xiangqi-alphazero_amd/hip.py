@@ -273,14 +273,15 @@ def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:
 
 
 def wino_conv3x3(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, residual=None,
-                 relu: bool = True) -> torch.Tensor:
-    """x, out, residual: float32[B, 90, C] contiguous (NHWC); out must not alias x / residual."""
+                 relu: bool = True, reverse: bool = False) -> torch.Tensor:
+    """x, out, residual: float32[B, 90, C] contiguous (NHWC); out must not alias x / residual.  `reverse` walks the batch
+    back to front (identical results; see XQ_CONV_REVERSE)."""
     b, n, c = x.shape
     if n != 90 or not x.is_contiguous() or not out.is_contiguous() or out.shape != x.shape:
         raise XqError("wino_conv3x3: float32[B,90,C] contiguous tensors required")
     check(lib().xq_wino_conv3x3(x.data_ptr(), u.data_ptr(), bias.data_ptr(),
-                                None if residual is None else residual.data_ptr(), out.data_ptr(), b, c, int(relu),
-                                stream_ptr(x.device)), "xq_wino_conv3x3")
+                                None if residual is None else residual.data_ptr(), out.data_ptr(), b, c,
+                                int(relu) | (2 if reverse else 0), stream_ptr(x.device)), "xq_wino_conv3x3")
     return out
 
 

@@ -38,6 +38,7 @@ class HipResNetEvaluator:
         self._bufs = None
         self._logits = None          # engine_policy: persistent [B, 8100] rows, -inf outside the reachable columns
         self._legal = None           # evaluate_legal: persistent [B, 128] legal-move logits
+        self.alternate_order = True  # XQ_CONV_REVERSE on every other conv launch (Infinity Cache reuse between layers)
         self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []
@@ -93,11 +94,12 @@ class HipResNetEvaluator:
         t0, t1, t2, t3 = self._buffers(b)
         h = hip.stem_conv(x.contiguous(), self.wt_in, self.b_in, t0)
         free = [t1, t2, t3]
-        for u1, b1, u2, b2 in self.blocks:
+        rev = self.alternate_order                                   # launches alternate front-to-back / back-to-front:
+        for u1, b1, u2, b2 in self.blocks:                           # each starts on what the previous one wrote last
             y = next(t for t in free if t.data_ptr() != h.data_ptr())
-            self._conv(h, u1, b1, y, None)
+            self._conv(h, u1, b1, y, None, rev)
             o = next(t for t in free if t.data_ptr() != h.data_ptr() and t.data_ptr() != y.data_ptr())
-            self._conv(y, u2, b2, o, h)
+            self._conv(y, u2, b2, o, h, False)
             h = o
         return hip.heads_1x1(h.view(b * 90, self.C), self.w_pv, self.b_pv)
 
@@ -115,15 +117,15 @@ class HipResNetEvaluator:
         value = hip.value_head(v.view(b, 360), self.fc_v1_wt, self.fc_v1_b, self.fc_v2_vec, self.fc_v2_b)
         return legal, value
 
-    def _conv(self, x, u, b, out, residual):
+    def _conv(self, x, u, b, out, residual, reverse=False):
         if self.timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            hip.wino_conv3x3(x, u, b, out, residual, True)
+            hip.wino_conv3x3(x, u, b, out, residual, True, reverse)
             e1.record()
             self._events.append((e0, e1))
         else:
-            hip.wino_conv3x3(x, u, b, out, residual, True)
+            hip.wino_conv3x3(x, u, b, out, residual, True, reverse)
 
     def roofline(self, batch: int, nn_ms: float):
         """bench.py roofline object for the dominant kernel (k_wino_conv): algorithmic FLOPs of the 3x3 convolution
