@@ -201,3 +201,55 @@ def test_full_loop_two_ranks_share_one_gpu(tmp_path):
     out = [open(tmp_path / ("gloop%d" % r)).read().split() for r in range(2)]
     assert out[0][0] == "1" and out[1][0] == "1", out
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+
+
+def _ddp_rank(rank, world, port, tmp):
+    import types
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xiangqi_alphazero_amd import model, training, weights
+    t = _trace()
+    game = [x for x in G.game_traces() if x["name"] == t["game"]][0]
+    arr, _ = _oracle_game_as_compact(game)
+    buf = training.ReplayBuffer(50000)
+    buf.extend(arr)
+    net = model.XiangqiNet(*t["net"])
+    net.load_state_dict(weights.make_state_dict(*t["net"], seed=t["seed"]))
+    net = net.cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=t["lr"], weight_decay=t["weight_decay"])
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=t["milestones"], gamma=t["gamma"])
+    cfg = types.SimpleNamespace(min_buffer_size=10, num_epochs=t["num_epochs"], batch_size=t["batch_size"])
+    stats = training.train_network(net, opt, sch, buf, cfg, shuffle=False, ddp=True)
+    sd = net.state_dict()
+    out = {"stats": stats, "probe": {k: [float(x) for x in sd[k].flatten()[:8].double().cpu()] for k in t["probe"]},
+           "nbt": int(sd["input_conv.1.num_batches_tracked"]), "keys": list(sd.keys())}
+    json.dump(out, open(os.path.join(tmp, "ddp%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ddp_train_step_matches_reference_trace(tmp_path):
+    """train.py:376-447 computed DATA-PARALLEL (world_size 2 over gloo, both ranks on the test box's one GPU): every batch
+    split across the ranks, SyncBatchNorm, DDP gradient all-reduce.  Against the SAME recorded run of the reference's
+    single-device train_network as the world-1 test: losses within 1e-4 relative, probed weights within 1e-4; both ranks
+    end with the same weights; the state_dict keeps the reference's keys."""
+    import socket
+    import torch.multiprocessing as mp
+    from xiangqi_alphazero_amd import weights
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t = _trace()
+    outs = [json.load(open(tmp_path / ("ddp%d.json" % r))) for r in range(2)]
+    for o in outs:
+        for k in ("policy_loss", "value_loss", "total_loss", "learning_rate"):
+            assert abs(o["stats"][k] - t["stats"][k]) <= 1e-4 * abs(t["stats"][k]) + 1e-7, (k, o["stats"][k], t["stats"][k])
+        assert o["nbt"] == t["num_batches_tracked"]
+        for k, want in t["probe"].items():
+            np.testing.assert_allclose(o["probe"][k], want, rtol=0, atol=1e-4, err_msg=k)
+        assert o["keys"] == list(weights.state_dict_shapes(*t["net"]).keys())
+    assert outs[0]["probe"] == outs[1]["probe"]

@@ -14,6 +14,8 @@ single-position protocol -- always uses); that one linear layer is a ROCm librar
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -38,7 +40,8 @@ class HipResNetEvaluator:
         self._bufs = None
         self._logits = None          # engine_policy: persistent [B, 8100] rows, -inf outside the reachable columns
         self._legal = None           # evaluate_legal: persistent [B, 128] legal-move logits
-        self.alternate_order = True  # XQ_CONV_REVERSE on every other conv launch (Infinity Cache reuse between layers)
+        # XQ_CONV_REVERSE on every other conv launch (Infinity Cache reuse between layers); XQ_CONV_ALTERNATE=0 for A/B runs
+        self.alternate_order = os.environ.get("XQ_CONV_ALTERNATE", "1") != "0"
         self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []

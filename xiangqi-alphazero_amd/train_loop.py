@@ -6,8 +6,9 @@ Per iteration, exactly the reference's order:
                    current best weights (no collective during search); the finished compact samples stay on the device
                    (`xq_engine_drain_device`) and one padded all-gather of those device buffers brings every rank's
                    records to every rank's device-resident replay buffer;
-  2. train         rank 0 runs `train_network` on its replay buffer; the new weights reach the other ranks as ONE flat
-                   `broadcast_weights`;
+  2. train         `train_network` data-parallel over the ranks (every batch split, SyncBatchNorm, bucketed gradient
+                   all-reduce: the reference's full-batch update) -- or on rank 0 alone with `config.ddp = False` -- then
+                   ONE flat `broadcast_weights`;
   3. arena gate    every second iteration (train.py:609) the candidate plays the best model, the games sharded over the
                    ranks (`arena.evaluate_models`); promote at win_rate >= eval_win_rate, else the candidate reverts to
                    the best weights (train.py:525-533).  Every rank derives the verdict from the same all-reduced table
@@ -82,9 +83,14 @@ class AlphaZeroLoop:
                 "total_time": time.time() - t0, "num_workers": self.world, "mode": "hip", "buffer_size": len(self.buffer)}
 
     def train_network(self) -> dict:
+        """World 1: the reference's step.  World > 1: the same full-batch update computed data-parallel -- every rank
+        holds the same buffer and weights, takes its slice of every batch, SyncBatchNorm + bucketed gradient all-reduce
+        (`training.train_network(ddp=True)`); `config.ddp = False` falls back to training on rank 0 alone.  Either way one
+        flat weight broadcast from rank 0 closes the step, so the replicas cannot drift."""
         stats = {}
-        if self.rank == 0:
-            stats = training.train_network(self.current_model, self.optimizer, self.scheduler, self.buffer, self.config)
+        ddp = self.world > 1 and bool(getattr(self.config, "ddp", True)) and self.device.type == "cuda"
+        if ddp or self.rank == 0:
+            stats = training.train_network(self.current_model, self.optimizer, self.scheduler, self.buffer, self.config, ddp=ddp)
         if self.world > 1:
             xdist.broadcast_weights(self.current_model, src=0, device=self.device)
         return stats

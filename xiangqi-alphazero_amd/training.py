@@ -79,28 +79,61 @@ class ReplayBuffer:
 
 
 def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shuffle: bool = True,
-                  generator: Optional[torch.Generator] = None) -> Dict[str, float]:
-    """One call of the reference's train_network (train.py:376-447) on the device-resident buffer."""
+                  generator: Optional[torch.Generator] = None, ddp: bool = False, group=None) -> Dict[str, float]:
+    """One call of the reference's train_network (train.py:376-447) on the device-resident buffer.
+
+    `ddp=True` under torch.distributed (every rank holds the same buffer and the same weights, as AlphaZeroLoop keeps
+    them): every batch is split across the ranks, BatchNorm statistics are synchronised (SyncBatchNorm: the batch
+    statistics of the WHOLE batch, as on the reference's single device) and the gradients are summed by bucketed
+    all-reduce overlapped with backward (DistributedDataParallel) -- the update is the reference's full-batch update, the
+    replicas stay identical, and each GPU runs 1/world of the forward/backward work.  The batch order comes from
+    `generator` (or a generator seeded identically on every rank)."""
     if len(buffer) < config.min_buffer_size:
         return {}
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (ddp and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
     n = len(buffer)
     model.train()
+    net = model
+    if world > 1:
+        torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, group)       # in place for the children; same Parameters
+        net = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[buffer.device.index] if buffer.device.type == "cuda" else None, process_group=group,
+            broadcast_buffers=False)
+        if generator is None:                                              # one order for all ranks
+            generator = torch.Generator().manual_seed(int(scheduler.last_epoch) * 7919 + 17)
     total_p = total_v = 0.0
     batches = 0
     for _ in range(config.num_epochs):
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         for lo in range(0, n, config.batch_size):                     # drop_last=False
-            states, target_pi, target_z = buffer.batch(order[lo:lo + config.batch_size])
-            logits, value = model(states)
-            policy_loss = -torch.mean(torch.sum(target_pi * F.log_softmax(logits, dim=1), dim=1))
-            value_loss = F.mse_loss(value, target_z)
-            loss = policy_loss + value_loss
+            idx = order[lo:lo + config.batch_size]
+            full = idx.numel()
+            scale = 1.0
+            if world > 1 and full >= world:                            # this rank's slice of the batch
+                idx = idx.tensor_split(world)[rank]
+                scale = float(world)                                   # DDP averages the ranks' gradients
+            states, target_pi, target_z = buffer.batch(idx)
+            logits, value = net(states)
+            if world > 1 and full >= world:
+                # sums over the local slice, scaled so that DDP's average over ranks is the full-batch mean loss
+                policy_loss = -torch.sum(target_pi * F.log_softmax(logits, dim=1)) / full
+                value_loss = torch.sum((value - target_z) ** 2) / full
+                loss = (policy_loss + value_loss) * scale
+            else:                                                      # the reference's expressions (train.py:409-413)
+                policy_loss = -torch.mean(torch.sum(target_pi * F.log_softmax(logits, dim=1), dim=1))
+                value_loss = F.mse_loss(value, target_z)
+                loss = policy_loss + value_loss
             optimizer.zero_grad()
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             optimizer.step()
-            total_p += policy_loss.item()
-            total_v += value_loss.item()
+            pv = torch.stack([policy_loss.detach(), value_loss.detach()])
+            if world > 1 and full >= world:
+                dist.all_reduce(pv, group=group)                       # the slices' shares add up to the batch's losses
+            total_p += pv[0].item()
+            total_v += pv[1].item()
             batches += 1
     scheduler.step()
     return {"policy_loss": total_p / max(batches, 1), "value_loss": total_v / max(batches, 1),
