@@ -21,7 +21,9 @@ rank runs its own 8192 games; no collective in the data path.  The same line als
     synthetic variant), unless --no-peaked;
   * "games_per_hour_measured": COMPLETE games under the reference's termination rules at BASELINE configs[1]
     (1024 games, 400 sims/move, 128x6) played inside this run, unless --complete-games 0;
-  * "cpu_baseline" (N = 1, rank 0): the reference's mode-1 worker restated on the host cores.
+  * "cpu_baseline" (N = 1, rank 0): the reference's mode-1 worker restated on the host cores;
+  * "throughput_mode" (only with --throughput-mode): a labelled REDUCED-PRECISION second measurement (bf16, ROCm library
+    convolutions) -- never the headline, outside the 1e-5 contract.
 """
 import argparse
 import json
@@ -66,7 +68,9 @@ def parse_args():
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--evaluator", default="hip", choices=["hip", "torch", "nhwc"])
+    ap.add_argument("--evaluator", default="hip", choices=["hip", "torch", "nhwc", "bf16"])
+    ap.add_argument("--throughput-mode", action="store_true",
+                    help="add a second, labelled measurement with the reduced-precision (bf16, ROCm library) evaluator")
     ap.add_argument("--peaked", action="store_true", help="headline measurement itself on peaked-policy weights")
     ap.add_argument("--no-peaked", action="store_true", help="skip the second (peaked) measurement")
     ap.add_argument("--complete-games", type=int, default=1024,
@@ -265,7 +269,7 @@ def complete_games_leg(args, dev, rank, world, dist, backend):
         parts = [mine]
     wall = max(p[0] for p in parts)
     n_games = sum(p[1] for p in parts)
-    return {"config": "BASELINE configs[1] per GPU: %d complete games, 1024 slots, 400 sims/move, 128x6" % games,
+    return {"config": "BASELINE configs[1] per GPU: %d complete games, %d slots, 400 sims/move, 128x6" % (games, min(games, 1024)),
             "games_finished": int(n_games), "wall_s": round(wall, 2), "games_per_hour": round(n_games * 3600.0 / wall, 1),
             "simulations_per_s": round(sum(p[2] for p in parts) / wall, 1),
             "mean_plies_per_game": round(sum(p[3] for p in parts) / max(n_games, 1), 2),
@@ -314,6 +318,13 @@ def main():
         mp = measure(args, dev, rank, world, dist, backend, True)
         mp_el, mp_sims, mp_rank = reduce_ranks(mp, dev, world, dist, backend)
     gph = complete_games_leg(args, dev, rank, world, dist, backend) if args.complete_games > 0 else None
+    mt = None
+    if args.throughput_mode and args.evaluator != "bf16":
+        saved = args.evaluator
+        args.evaluator = "bf16"
+        mt = measure(args, dev, rank, world, dist, backend, args.peaked)
+        mt_el, mt_sims, _ = reduce_ranks(mt, dev, world, dist, backend)
+        args.evaluator = saved
 
     if rank == 0:
         flops_eval, _ = net_flops(args.channels, args.blocks)
@@ -364,6 +375,13 @@ def main():
                              "breakdown_ms": {"select": round(mp["sel_ms"], 3), "evaluate": round(mp["nn_ms"], 3),
                                               "expand_backup": round(mp["exp_ms"], 3)},
                              "tree": ptree, "tree_roofline": ptree_roof}
+        if mt is not None:
+            out["throughput_mode"] = {"label": "REDUCED PRECISION, not the headline and outside the 1e-5 contract: bf16 weights/activations on the "
+                                               "ROCm library's bf16 MFMA convolutions (evaluator.Bf16ThroughputEvaluator)",
+                                      "dtype": "bf16", "value": round(mt_sims / mt_el, 1), "unit": "simulations/s",
+                                      "ms_per_step": round(1e3 * mt_el / args.steps, 3), "evaluator": mt["ev_name"],
+                                      "breakdown_ms": {"select": round(mt["sel_ms"], 3), "evaluate": round(mt["nn_ms"], 3),
+                                                       "expand_backup": round(mt["exp_ms"], 3)}}
         # games/hour: measured on complete games at configs[1] (above); at this line's own configuration no game can finish
         # inside a bench run (one ply of all games = sims+1 steps), so that figure is DERIVED from the measured simulation
         # rate and the game length measured in this same run.

@@ -357,3 +357,23 @@ def test_evaluate_legal_matches_dense_logits_on_engine_requests():
     assert bool((counts[waiting & (phase == 4)] > 0).all())               # a leaf request always has legal moves
     eng.expand_legal(ll, value)
     assert eng.stats()["overflow"] == 0
+
+
+def test_bf16_throughput_mode_is_labelled_and_outside_the_contract():
+    """The reduced-precision evaluator (bench.py --throughput-mode) on the golden positions: it tracks the reference
+    loosely (value within 3e-2, top-1 policy move mostly the same) and -- stated here so nobody mistakes it for the parity
+    path -- MISSES the 1e-5 contract by orders of magnitude."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    g = G.nn_golden()
+    states = torch.from_numpy(_golden_states(g)).cuda()
+    net = model.XiangqiNet(128, 6)
+    net.load_state_dict(weights.make_state_dict(128, 6))
+    ev, name = evaluator.make_evaluator(net, "cuda", "bf16")
+    assert "bf16" in name and "throughput" in name
+    logits, v = ev(states)
+    assert logits.dtype == torch.float32 and logits.shape == (len(states), 8100)
+    err_v = np.abs(v.cpu().numpy() - g["128x6_value"]).max()
+    assert 1e-5 < err_v < 3e-2, err_v
+    probs = torch.softmax(logits, 1).cpu().numpy()
+    assert np.abs(np.take_along_axis(probs, g["128x6_top_idx"], axis=1) - g["128x6_top_prob"]).max() > 1e-5

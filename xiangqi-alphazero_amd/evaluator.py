@@ -63,7 +63,35 @@ def make_evaluator(net: XiangqiNet, device, kind: str = "hip"):
         return ChannelsLastEvaluator(net, device), "rocm-igemm-nhwc-f32+hip-epilogue"
     if kind == "torch":
         return BatchedEvaluator(net, device), "torch-rocm-f32"
+    if kind == "bf16":
+        return Bf16ThroughputEvaluator(net, device), "rocm-library-bf16-throughput-mode"
     raise ValueError("unknown evaluator kind %r" % (kind,))
+
+
+class Bf16ThroughputEvaluator:
+    """REDUCED-PRECISION throughput mode (hard parts: "keep an fp32 parity mode and a bf16 throughput
+    mode, report both"): the same folded network with bf16 weights and activations on the ROCm library's bf16 MFMA
+    convolutions (channels-last), fp32 accumulation inside the library kernels, fp32 heads' outputs.  It does NOT meet the
+    1e-5 contract (bf16 carries 8 significand bits; tests/test_nn_fullsize.py states the measured deviation) and is never
+    the headline: bench.py reports it as a second, labelled object.  Library kernels only -- comparison material, not
+    credited as hand-written implementation."""
+
+    def __init__(self, net: XiangqiNet, device="cuda"):
+        self.device = torch.device(device)
+        self.update(net)
+
+    def update(self, net: XiangqiNet):
+        self.net = InferenceNet(net).to(self.device).to(torch.bfloat16).to(memory_format=torch.channels_last).eval()
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        logits, value = self.net(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        return logits.float(), value.float().view(-1)
+
+    def predict(self, state: np.ndarray, device=None):
+        x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
+        logits, value = self(x)
+        return torch.softmax(logits, dim=1).squeeze(0).cpu().numpy(), float(value.item())
 
 
 class ChannelsLastEvaluator:
