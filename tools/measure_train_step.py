@@ -56,8 +56,8 @@ def main():
     gpu_rate = a.epochs * len(buf) / gpu_s
 
     # the reference's step on the host: dense tuples, DataLoader-style batches, same math (train.py:398-419)
-    if a.cpu_threads > 0:
-        torch.set_num_threads(a.cpu_threads)
+    from oracle.cpu_baseline import host_cores                         # CPUs this job is actually granted (cgroup quota)
+    torch.set_num_threads(a.cpu_threads if a.cpu_threads > 0 else host_cores())
     dense, _ = to_reference_tuples(samples[:a.cpu_batches * a.batch // 2 + 1], results, augment=True)
     dense = dense[:a.cpu_batches * a.batch]
     cpu_net = model.XiangqiNet(a.channels, a.blocks)

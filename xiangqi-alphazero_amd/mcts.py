@@ -32,6 +32,15 @@ class MCTS:
             ev_mod.make_evaluator(model, device, evaluator_kind)[0]
         self._engines = {}
 
+    def refresh(self, model=None):
+        """Re-fold the weights after the caller changed its model in place (or hand over a new one).  The reference's
+        MCTS reads the live model on every `.predict`; this shim snapshots BN-folded / pre-transformed weights, so a
+        caller that keeps training between searches calls this first."""
+        if model is not None:
+            self.model = model
+        if hasattr(self.evaluator, "update") and hasattr(self.model, "state_dict"):
+            self.evaluator.update(self.model)
+
     def _engine(self, n: int, add_noise: bool):
         key = (n, add_noise)
         if key not in self._engines:
