@@ -132,10 +132,11 @@ def _engine_planes(games, sims, prewarm):
     return x
 
 
-@pytest.mark.parametrize("ch,nb,games", [(256, 10, 8192), (128, 6, 1024)])
+@pytest.mark.parametrize("ch,nb,games", [(256, 10, 8192), (128, 6, 1024), (256, 20, 8192)])
 def test_hip_evaluator_on_engine_planes_at_bench_batch(ch, nb, games):
-    """BASELINE configs[2] / configs[1]: the evaluator the bench times, on the batch the bench times, against the
-    float64 evaluation of the same folded weights: logits within 2e-5, value within 1e-5, softmax within 1e-5."""
+    """BASELINE configs[2] / configs[1] / one GPU's share of configs[3] (256x20): the evaluator the bench times, on the
+    batch the bench times, against the float64 evaluation of the same folded weights: logits within 2e-5, value within
+    1e-5, softmax within 1e-5."""
     import torch
     from xiangqi_alphazero_amd import evaluator, model, weights
     x = _engine_planes(games, 48, 64)
