@@ -49,3 +49,28 @@ def test_parallel_self_play_schema_and_rules():
     assert abs(pi1.sum() - pi0.sum()) < 1e-15 and np.count_nonzero(pi1) == np.count_nonzero(pi0)
     assert stats["avg_steps"] <= 200 and stats["simulations"] >= 12 * QuickConfig.num_simulations
     del torch
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """engine.capture_step: a HIP-graph replay of select -> evaluator -> expand must leave the engine in exactly the state
+    eager launches do -- same seeds, same network, 300 steps: identical counters, samples and results."""
+    import numpy as np
+    import torch
+    from xiangqi_alphazero_amd import engine, evaluator, model, weights
+    net = model.XiangqiNet(64, 3)
+    net.load_state_dict(weights.make_state_dict(64, 3, policy_gain=4.0))
+    out = []
+    for graph in (False, True):
+        ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
+        cfg = engine.make_config(96, 12, max_game_length=40, random_opening_moves=4, temperature_threshold=8, seed=21)
+        eng = engine.SelfPlayEngine(cfg, "cuda", evaluator=ev)
+        if graph:
+            assert eng.capture_step(warmup=2)
+        for _ in range(300 - (2 if graph else 0)):
+            eng.step()
+        st = eng.stats()
+        smp, res = eng.drain()
+        out.append((st, smp, res))
+    (s0, a0, r0), (s1, a1, r1) = out
+    assert s0 == s1 and s0["games_finished"] > 20 and s0["overflow"] == 0
+    assert a0.tobytes() == a1.tobytes() and r0.tobytes() == r1.tobytes()

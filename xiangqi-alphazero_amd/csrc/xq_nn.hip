@@ -235,11 +235,11 @@ __global__ __launch_bounds__(256) void k_policy_legal(const float *__restrict__ 
 }
 
 // Value head's fully connected layers (model.py:73-85: Linear(360, 128) + ReLU + Linear(128, 1) + tanh) over the value
-// features float[G][90][4] that k_heads_1x1 wrote.  16 games per 128-thread block: the games' features sit in LDS,
-// thread j owns hidden unit j for all 16 games and streams its weight column (w1t[k][j]: coalesced, L2-resident 184 KB),
+// features float[G][90][4] that k_heads_1x1 wrote.  VGB games per 128-thread block: the games' features sit in LDS,
+// thread j owns hidden unit j for the block's games and streams its weight column (w1t[k][j]: coalesced, L2-resident 184 KB),
 // the 128 -> 1 layer is a wave reduction.  A 0.75 GFLOP problem at G = 8192: microseconds; it exists so that the
 // evaluator makes no library call.
-constexpr int VGB = 16;
+constexpr int VGB = 4;        // games per block: 4 keeps >= 256 blocks in flight from G = 1024 up (16: 47 us at G = 1024)
 __global__ __launch_bounds__(128) void k_value_head(const float *__restrict__ vf, const float *__restrict__ w1t,
                                                     const float *__restrict__ b1, const float *__restrict__ w2,
                                                     const float *__restrict__ b2, int games, float *__restrict__ value) {

@@ -82,6 +82,7 @@ class SelfPlayEngine:
         self.req_moves = self.ws[mo:mo + self.G * hip.MAXM * 2].view(torch.int16).view(self.G, hip.MAXM)
         self.req_counts = self.ws[co:co + self.G * 4].view(torch.int32)
         self.steps = 0
+        self._graph = None
 
     # ---- the three stages of a step --------------------------------------------------------------------
     def select(self):
@@ -125,9 +126,40 @@ class SelfPlayEngine:
             self.expand(logits, value, False)
 
     def step(self):
-        """select -> evaluator -> expand, all asynchronous on the current stream."""
-        self.evaluate_and_expand(self.select())
+        """select -> evaluator -> expand, all asynchronous on the current stream (one graph launch once `capture_step`
+        has recorded it)."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self.evaluate_and_expand(self.select())
         self.steps += 1
+
+    def capture_step(self, warmup: int = 2) -> bool:
+        """Record one step (xq_engine_select, every evaluator kernel, xq_engine_expand[_legal]) into a HIP graph and make
+        `step()` replay it: one launch per step instead of ~2B+8 launches issued from Python.  All kernel arguments of a
+        step are constants of the engine (the workspace, the evaluator's persistent buffers), so the recording stays valid
+        until the evaluator's weights are replaced (`release_graph()` then).  Matters where steps are short: at BASELINE
+        configs[1] (1024 games, 128x6) the launches of an eager step leave the GPU idle for ~17 % of it; at configs[2] a
+        step is 52 ms and the gain is nil.  `warmup` eager steps run first (allocations, function attributes).  Returns
+        False, and stays eager, for evaluators that are not capturable (they synchronise or allocate outside torch)."""
+        if self.evaluator is None:
+            raise hip.XqError("capture_step needs an evaluator")
+        for _ in range(warmup):
+            self.evaluate_and_expand(self.select())
+            self.steps += 1
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self.evaluate_and_expand(self.select())
+        except Exception:
+            torch.cuda.synchronize(self.device)
+            return False
+        self._graph = g
+        return True
+
+    def release_graph(self):
+        self._graph = None
 
     # ---- bookkeeping --------------------------------------------------------------------------------------
     def stats(self, check: bool = True) -> dict:

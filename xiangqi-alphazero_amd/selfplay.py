@@ -23,7 +23,7 @@ _CFG_KEYS = ("num_simulations", "c_puct", "temperature_threshold", "max_game_len
 
 
 def run_games(model, config, num_games: int, device="cuda", n_slots: Optional[int] = None, seed: int = 0, rank: int = 0,
-              evaluator_kind: str = "hip", poll_every: int = 64, device_records: bool = False):
+              evaluator_kind: str = "hip", poll_every: int = 64, device_records: bool = False, use_graph: bool = True):
     """Play `num_games` complete games; returns (samples, results, stats dict, elapsed seconds) in compact form:
     structured numpy arrays, or -- `device_records` -- uint8 device tensors [n, 640] / [m, 16] that never left the GPU."""
     slots = int(n_slots or min(num_games, 8192))
@@ -38,6 +38,8 @@ def run_games(model, config, num_games: int, device="cuda", n_slots: Optional[in
         max_out_samples=num_games * 201, max_out_results=num_games + 8)
     eng = engine.SelfPlayEngine(cfg, device, evaluator=ev)
     t0 = time.time()
+    if use_graph and hasattr(ev, "evaluate_legal"):
+        eng.capture_step()                             # one graph launch per step (short steps are launch-bound otherwise)
     while True:
         for _ in range(poll_every):
             eng.step()
