@@ -62,7 +62,7 @@ def test_graph_replayed_steps_equal_eager_steps():
     out = []
     for graph in (False, True):
         ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
-        cfg = engine.make_config(96, 12, max_game_length=40, random_opening_moves=4, temperature_threshold=8, seed=21)
+        cfg = engine.make_config(96, 4, max_game_length=20, random_opening_moves=4, temperature_threshold=8, seed=21)
         eng = engine.SelfPlayEngine(cfg, "cuda", evaluator=ev)
         if graph:
             assert eng.capture_step(warmup=2)
