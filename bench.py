@@ -76,6 +76,8 @@ def parse_args():
     ap.add_argument("--complete-games", type=int, default=1024,
                     help="games of the measured games/hour leg (BASELINE configs[1]; 0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--graph", action="store_true",
+                    help="time HIP-graph replays of the step (engine.capture_step) instead of eager launches; no per-stage breakdown")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--prewarm", type=int, default=-1,
                     help="untimed network-free steps that bring the staggered slots to the steady-state mix of search "
@@ -164,11 +166,15 @@ def measure(args, dev, rank, world, dist, backend, peaked):
         eng.step()
     sync()
     s0 = eng.stats()
-    if hasattr(ev, "timing"):
+    graphed = bool(args.graph and sparse and eng.capture_step(warmup=0))
+    if hasattr(ev, "timing") and not graphed:
         ev.timing = True            # HIP events around each launch of the dominant kernel, timed region only
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if graphed:
+            eng.step()
+            continue
         e = ev_t[4 * k:4 * k + 4]
         e[0].record()
         x = eng.select()
@@ -188,14 +194,17 @@ def measure(args, dev, rank, world, dist, backend, peaked):
     if hasattr(ev, "timing"):
         ev.timing = False
     n = args.steps
-    sel_ms = sum(ev_t[4 * k].elapsed_time(ev_t[4 * k + 1]) for k in range(n)) / n
-    nn_ms = sum(ev_t[4 * k + 1].elapsed_time(ev_t[4 * k + 2]) for k in range(n)) / n
-    exp_ms = sum(ev_t[4 * k + 2].elapsed_time(ev_t[4 * k + 3]) for k in range(n)) / n
+    if graphed:                     # one graph launch per step: no per-stage events; the whole step is booked as "evaluate"
+        sel_ms, exp_ms, nn_ms = 1e-9, 1e-9, 1e3 * elapsed / n
+    else:
+        sel_ms = sum(ev_t[4 * k].elapsed_time(ev_t[4 * k + 1]) for k in range(n)) / n
+        nn_ms = sum(ev_t[4 * k + 1].elapsed_time(ev_t[4 * k + 2]) for k in range(n)) / n
+        exp_ms = sum(ev_t[4 * k + 2].elapsed_time(ev_t[4 * k + 3]) for k in range(n)) / n
     d = {k: s1[k] - s0[k] for k in ("sims", "depth_sum", "children_scanned", "nodes_created", "leaf_evals", "root_evals",
                                     "terminal_sims")}
-    roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
+    roof = ev.roofline(args.games, nn_ms) if (hasattr(ev, "roofline") and not graphed) else None
     out = dict(elapsed=elapsed, sims=d["sims"], sel_ms=sel_ms, nn_ms=nn_ms, exp_ms=exp_ms, d=d, roof=roof, ev_name=ev_name,
-               prewarm=prewarm, sparse=sparse)
+               prewarm=prewarm, sparse=sparse, graphed=graphed)
     del eng, ev
     torch.cuda.empty_cache()
     return out
@@ -358,6 +367,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_label(args), "games_per_gpu": args.games, "sims_per_move": args.sims,
                        "net": "%dx%d" % (args.channels, args.blocks), "evaluator": m["ev_name"], "policy_handoff": "legal-move logits [G,128]" if m["sparse"] else "dense logits [G,8100]",
+                       "launch": "HIP-graph replay, one launch per step" if m["graphed"] else "eager kernel launches",
                        "prewarm_steps": m["prewarm"],
                        "parallelism": "games sharded across ranks, no data-path collective"},
             "ranks": {"launched_by": "bench.py" if os.environ.get("XQ_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
