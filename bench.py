@@ -112,6 +112,21 @@ def launch_ranks(args) -> int:
     return rc
 
 
+def smi_sample(box):
+    """One `rocm-smi` reading of the engine clock and the socket power WHILE the timed steps run (a child process; it does
+    not touch the GPU from this one).  The boards are power-capped: under the fp32 MFMA tower the engine clock settles
+    near 2.2 GHz of the nominal 2.4, which scales the MFMA peak that is actually available."""
+    import re
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
+        w = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+        box["sclk_mhz"] = int(m.group(1)) if m else None
+        box["power_w"] = float(w.group(1)) if w else None
+    except Exception:
+        box["sclk_mhz"] = box["power_w"] = None
+
+
 class PseudoPolicy:
     """Network-free evaluator of the untimed prewarm: logits = gain * (planes . R) with a fixed seeded R, value 0.
     gain 0 -> uniform priors (shallow, wide trees); gain > 0 -> peaked priors (deep, narrow trees), so the slots reach the
@@ -166,10 +181,15 @@ def measure(args, dev, rank, world, dist, backend, peaked):
         eng.step()
     sync()
     s0 = eng.stats()
+    import threading
+    smi = {}
+    smi_thread = threading.Thread(target=smi_sample, args=(smi,)) if rank == 0 else None
     graphed = bool(args.graph and sparse and eng.capture_step(warmup=0))
     if hasattr(ev, "timing") and not graphed:
         ev.timing = True            # HIP events around each launch of the dominant kernel, timed region only
     sync()
+    if smi_thread is not None:
+        smi_thread.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if graphed:
@@ -190,6 +210,8 @@ def measure(args, dev, rank, world, dist, backend, peaked):
         e[3].record()
     sync()
     elapsed = time.perf_counter() - t0
+    if smi_thread is not None:
+        smi_thread.join()
     s1 = eng.stats()
     if hasattr(ev, "timing"):
         ev.timing = False
@@ -204,7 +226,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
                                     "terminal_sims")}
     roof = ev.roofline(args.games, nn_ms) if (hasattr(ev, "roofline") and not graphed) else None
     out = dict(elapsed=elapsed, sims=d["sims"], sel_ms=sel_ms, nn_ms=nn_ms, exp_ms=exp_ms, d=d, roof=roof, ev_name=ev_name,
-               prewarm=prewarm, sparse=sparse, graphed=graphed)
+               prewarm=prewarm, sparse=sparse, graphed=graphed, smi=smi)
     del eng, ev
     torch.cuda.empty_cache()
     return out
@@ -358,6 +380,12 @@ def main():
             roof = {"bound": "mfma", "kernel": "ResNet forward (%s), whole-network FLOPs / event-timed forward" % m["ev_name"],
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None}
+        if m["smi"].get("sclk_mhz") and roof.get("bound") == "mfma":
+            # the peak the silicon offers at the clock the power cap left DURING the timed steps (nominal: 2400 MHz)
+            mhz = m["smi"]["sclk_mhz"]
+            roof["sclk_mhz_during_timed_steps"] = mhz
+            roof["socket_power_w"] = m["smi"].get("power_w")
+            roof["frac_of_peak_at_that_clock"] = round(roof["achieved"] / (PEAK_F32_MFMA * mhz / 2400.0), 4)
         tree, tree_roof = tree_block(args, m)
         value = sims_all / elapsed_max
         out = {
