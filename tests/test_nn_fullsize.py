@@ -378,3 +378,24 @@ def test_bf16_throughput_mode_is_labelled_and_outside_the_contract():
     assert 1e-5 < err_v < 3e-2, err_v
     probs = torch.softmax(logits, 1).cpu().numpy()
     assert np.abs(np.take_along_axis(probs, g["128x6_top_idx"], axis=1) - g["128x6_top_prob"]).max() > 1e-5
+
+
+def test_evaluator_update_refreshes_weights_in_place():
+    """`HipResNetEvaluator.update` (new weights for the next games, inference_server.py:476-487) must keep every device
+    pointer -- a HIP graph recorded over the evaluator keeps replaying -- and must change the outputs to the new network's."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    g = G.nn_golden()
+    states = torch.from_numpy(_golden_states(g)).cuda()
+    a, b = model.XiangqiNet(64, 3), model.XiangqiNet(64, 3)
+    a.load_state_dict(weights.make_state_dict(64, 3, seed=5))
+    b.load_state_dict(weights.make_state_dict(64, 3))
+    ev, _ = evaluator.make_evaluator(a, "cuda", "hip")
+    ptrs = [t.data_ptr() for blk in ev.blocks for t in blk] + [ev.fc_p_w.data_ptr(), ev.wt_in.data_ptr(), ev.fc_v1_wt.data_ptr()]
+    la, va = ev(states, full_policy=True)
+    la = la.clone()
+    ev.update(b)
+    assert ptrs == [t.data_ptr() for blk in ev.blocks for t in blk] + [ev.fc_p_w.data_ptr(), ev.wt_in.data_ptr(), ev.fc_v1_wt.data_ptr()]
+    lb, vb = ev(states, full_policy=True)
+    assert (la - lb).abs().max().item() > 1e-2
+    np.testing.assert_allclose(vb.cpu().numpy(), g["64x3_value"], rtol=0, atol=TOL)

@@ -48,26 +48,39 @@ class HipResNetEvaluator:
         self.update(net)
 
     def update(self, net: XiangqiNet):
+        """(Re)build the folded / pre-transformed device weights.  After the first call every tensor is refreshed IN PLACE:
+        device pointers stay what they were, so a HIP graph recorded over this evaluator (`engine.capture_step`) keeps
+        replaying with the new weights (the reference's `InferenceServer.update_model`, inference_server.py:476-487)."""
         ref = InferenceNet(net)
-        dv = lambda t: t.to(self.device).contiguous()
-        self.wt_in = dv(hip.stem_weights(ref.w_in))                # [135, C] for xq_stem_conv
-        self.b_in = dv(ref.b_in)
-        self.blocks = []
+        new = {}
+        new["wt_in"] = hip.stem_weights(ref.w_in)                    # [135, C] for xq_stem_conv
+        new["b_in"] = ref.b_in
         for i in range(self.num_res_blocks):
-            self.blocks.append((hip.wino_transform_weights(getattr(ref, f"w1_{i}")).to(self.device), dv(getattr(ref, f"b1_{i}")),
-                                hip.wino_transform_weights(getattr(ref, f"w2_{i}")).to(self.device), dv(getattr(ref, f"b2_{i}"))))
+            new[f"u1_{i}"] = hip.wino_transform_weights(getattr(ref, f"w1_{i}"))
+            new[f"b1_{i}"] = getattr(ref, f"b1_{i}")
+            new[f"u2_{i}"] = hip.wino_transform_weights(getattr(ref, f"w2_{i}"))
+            new[f"b2_{i}"] = getattr(ref, f"b2_{i}")
         # both heads' 1x1 convolutions as one [36, C] matrix: rows 0-31 policy, 32-35 value (xq_heads_1x1)
-        self.w_pv = dv(torch.cat([ref.w_p.view(ref.w_p.shape[0], -1), ref.w_v.view(ref.w_v.shape[0], -1)], 0))
-        self.b_pv = dv(torch.cat([ref.b_p, ref.b_v], 0))
+        new["w_pv"] = torch.cat([ref.w_p.view(ref.w_p.shape[0], -1), ref.w_v.view(ref.w_v.shape[0], -1)], 0)
+        new["b_pv"] = torch.cat([ref.b_p, ref.b_v], 0)
         # heads consume NHWC rows: permute the FC weights once from the reference's (c, h, w) flatten order to (hw, c)
         fp = ref.fc_p_w.view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
         fv = ref.fc_v1_w.view(-1, 4, 90).permute(0, 2, 1).reshape(-1, 360)
-        self.fc_p_w, self.fc_p_b = dv(fp), dv(ref.fc_p_b)
-        self.fc_pr_w, self.fc_pr_b = dv(self.fc_p_w[self.reach]), dv(self.fc_p_b[self.reach])
-        self.fc_v1_w, self.fc_v1_b = dv(fv), dv(ref.fc_v1_b)
-        self.fc_v2_w, self.fc_v2_b = dv(ref.fc_v2_w), dv(ref.fc_v2_b)
-        self.fc_v1_wt = dv(fv.t())                                   # [360, 128] for xq_value_head
-        self.fc_v2_vec = dv(ref.fc_v2_w.reshape(-1))
+        new["fc_p_w"], new["fc_p_b"] = fp, ref.fc_p_b
+        new["fc_pr_w"], new["fc_pr_b"] = fp[self.reach.cpu()], ref.fc_p_b[self.reach.cpu()]
+        new["fc_v1_w"], new["fc_v1_b"] = fv, ref.fc_v1_b
+        new["fc_v2_w"], new["fc_v2_b"] = ref.fc_v2_w, ref.fc_v2_b
+        new["fc_v1_wt"] = fv.t()                                     # [360, 128] for xq_value_head
+        new["fc_v2_vec"] = ref.fc_v2_w.reshape(-1)
+        for name, value in new.items():
+            value = value.detach().to(self.device, torch.float32).contiguous()
+            old = getattr(self, name, None)
+            if isinstance(old, torch.Tensor) and old.shape == value.shape:
+                old.copy_(value)
+            else:
+                setattr(self, name, value)
+        self.blocks = [(getattr(self, f"u1_{i}"), getattr(self, f"b1_{i}"), getattr(self, f"u2_{i}"), getattr(self, f"b2_{i}"))
+                       for i in range(self.num_res_blocks)]
 
     def _buffers(self, b):
         """Four NHWC activation buffers, grown to the largest batch seen (callers with a varying batch -- the arena
