@@ -224,7 +224,13 @@ def measure(args, dev, rank, world, dist, backend, peaked):
         exp_ms = sum(ev_t[4 * k + 2].elapsed_time(ev_t[4 * k + 3]) for k in range(n)) / n
     d = {k: s1[k] - s0[k] for k in ("sims", "depth_sum", "children_scanned", "nodes_created", "leaf_evals", "root_evals",
                                     "terminal_sims")}
-    roof = ev.roofline(args.games, nn_ms) if (hasattr(ev, "roofline") and not graphed) else None
+    if hasattr(ev, "roofline") and graphed:
+        # one launch per step, no per-kernel events: book the WHOLE step to the 2*blocks conv launches -- an upper bound on
+        # the launch time, so `frac` is a lower bound here
+        roof = ev.roofline(args.games, nn_ms, launch_ms=nn_ms / (2 * args.blocks))
+        roof["kernel"] += " [graph replay: whole step / %d launches, lower bound]" % (2 * args.blocks)
+    else:
+        roof = ev.roofline(args.games, nn_ms) if hasattr(ev, "roofline") else None
     out = dict(elapsed=elapsed, sims=d["sims"], sel_ms=sel_ms, nn_ms=nn_ms, exp_ms=exp_ms, d=d, roof=roof, ev_name=ev_name,
                prewarm=prewarm, sparse=sparse, graphed=graphed, smi=smi)
     del eng, ev

@@ -143,15 +143,18 @@ class HipResNetEvaluator:
         else:
             hip.wino_conv3x3(x, u, b, out, residual, True, reverse)
 
-    def roofline(self, batch: int, nn_ms: float):
+    def roofline(self, batch: int, nn_ms: float, launch_ms: float = None):
         """bench.py roofline object for the dominant kernel (k_wino_conv): algorithmic FLOPs of the 3x3 convolution
         it computes (2*90*9*C*C per position, SURVEY.md section 8a row a17 share) x positions per launch, over the
         average launch duration measured with HIP events on the launch stream."""
-        if not self._events:
+        if launch_ms is not None:          # no per-launch events (graph replay): the caller's upper bound on a launch
+            ms, avg = [], launch_ms
+        elif not self._events:
             return None
-        torch.cuda.synchronize(self.device)
-        ms = [a.elapsed_time(b) for a, b in self._events]
-        avg = sum(ms) / len(ms)
+        else:
+            torch.cuda.synchronize(self.device)
+            ms = [a.elapsed_time(b) for a, b in self._events]
+            avg = sum(ms) / len(ms)
         direct = 2.0 * 90 * 9 * self.C * self.C * batch
         tiles = (batch * 15 + 31) // 32 * 32
         mfma = 20 * 2.0 * tiles * self.C * self.C
