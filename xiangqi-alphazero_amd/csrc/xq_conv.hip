@@ -46,7 +46,8 @@
 // main loop, 2 no input transform (and no LDS reads of the raw input), 4 LDS reads kept but the transform's arithmetic
 // dropped, 8 no staging of the next chunks (global -> LDS), 16 no main-loop barriers, 32 no epilogue, 64 no MFMAs,
 // 128 staging loads from one contiguous run (coalesced), 256 staging loads from an L2-resident region, 512 staging issued
-// at the start of a chunk instead of its middle, 1024 weight loads always from chunk 0 (L1/L2-hot).
+// at the start of a chunk instead of its middle, 1024 weight loads always from chunk 0 (L1/L2-hot), 2048 two weight slices
+// per XCD, 4096 / 8192 weight loads sc1 (L1 bypass) / nt, 16384 output stores nt, 32768 residual loads nt.
 // Results are wrong by construction; only the launch time is read.
 #ifndef XQ_ABL
 #define XQ_ABL 0
@@ -84,6 +85,21 @@ constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// cache-policy variants (aux: bit 0 sc0, bit 1 nt, bit 4 sc1): weight fragments are read once per workgroup and never from
+// this CU's L1 again -- XQ_W_AUX selects how they pass through the caches
+#ifndef XQ_W_AUX
+#define XQ_W_AUX ((XQ_ABL & 4096) ? 16 : (XQ_ABL & 8192) ? 2 : 0)
+#endif
+__device__ __forceinline__ f32x4 buf_ld4_w(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, XQ_W_AUX));
+}
+__device__ __forceinline__ void st4_y(float *p, f32x4 v) {
+    if (XQ_ABL & 16384) __builtin_nontemporal_store(v, (f32x4 *)p); else *(f32x4 *)p = v;
+}
+__device__ __forceinline__ f32x4 ld4_r(const float *p) {
+    if (XQ_ABL & 32768) return __builtin_nontemporal_load((const f32x4 *)p);
+    return *(const f32x4 *)p;
 }
 // packed fp32 helpers on four floats (two instructions each); c is a {k, k} pair in SGPRs or VGPRs
 __device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b) {
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     // weight fragment f of a chunk: (q, nt) = (QO[f >> 1], f & 1), processing order of the column frequencies 1,2,3,0,4
     auto load_frag = [&](int chunk, int f, int slot) __attribute__((always_inline)) {
         const int q = (f >> 1) == 0 ? 1 : (f >> 1) == 1 ? 2 : (f >> 1) == 2 ? 3 : (f >> 1) == 3 ? 0 : 4;
-        ub[slot] = buf_ld4(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f & 1) * (32 * 16));
+        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f & 1) * (32 * 16));
     };
     auto transform0 = [&]() __attribute__((always_inline)) {
         f32x4 w[5];
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
         f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        resv[it] = (has_r && eok) ? *(const f32x4 *)(R + obase + ((it / 3) * 9 + it % 3) * C) : z;
+        resv[it] = (has_r && eok) ? ld4_r(R + obase + ((it / 3) * 9 + it % 3) * C) : z;
     }
     float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats
     float *ew = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;        // + compile-time offsets: immediates of the LDS ops
@@ -379,13 +395,13 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         }
         if (eok) {
 #pragma unroll
-            for (int it = 0; it < 6; ++it) *(f32x4 *)(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C) = yv[it];
+            for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
         }
         if (n == 0) {
             if (has_r && eok) {
 #pragma unroll
                 for (int it = 0; it < 6; ++it)        // residual of the second half: in flight during its exchange
-                    resv[it] = *(const f32x4 *)(R + obase + 32 + ((it / 3) * 9 + it % 3) * C);
+                    resv[it] = ld4_r(R + obase + 32 + ((it / 3) * 9 + it % 3) * C);
             }
             __syncthreads();                          // the second half overwrites the planes
         }
