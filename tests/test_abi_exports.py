@@ -47,6 +47,15 @@ def test_argument_errors_without_gpu():
     assert lib.xq_movegen_batch(None, None, 0, None, None, None, None, None) == 0     # empty batch is a no-op
     assert lib.xq_encode_batch(None, None, 3, None, None) == -1
     assert lib.xq_engine_select(None, None, None) == -1
+    # round-2 entry points: same conventions (null pointers / negative sizes -> XQ_ERR_ARG, empty batches are no-ops)
+    assert lib.xq_policy_head_legal(None, None, None, None, None, 4, None, None) == -1
+    assert lib.xq_policy_head_legal(None, None, None, None, None, 0, None, None) == 0
+    assert lib.xq_value_head(None, None, None, None, None, 2, None, None) == -1
+    assert lib.xq_value_head(None, None, None, None, None, 0, None, None) == 0
+    assert lib.xq_engine_expand_legal(None, None, None, None) == -1
+    assert lib.xq_engine_requests(None, None, None) == -1
+    assert lib.xq_engine_drain_device(None, None, 0, None, None, 0, None, None) == -1
+    assert lib.xq_wino_conv3x3(None, None, None, None, None, 8, 256, 1, None) == -1
 
 
 def test_product_path_has_no_cpu_fallback():
