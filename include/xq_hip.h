@@ -261,6 +261,9 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
  * that each launch first reads what the previous one wrote last, while it is still in the Infinity Cache). */
 #define XQ_CONV_RELU 1
 #define XQ_CONV_REVERSE 2
+/* bit 2: "wide" variant -- 128 output channels per workgroup (one workgroup per CU, 320 accumulators per wave): dev_u is then
+ * float32[C/128][C/8][20][2][128][4] (the same element formula with 128-channel blocks), channels in {128, 256, 512}. */
+#define XQ_CONV_WIDE 4
 
 /* =====================================================================================
  * Next row (section 8f.1) -- training-batch materialisation.  Replaces SelfPlayDataset.__getitem__ + augment_data

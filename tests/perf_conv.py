@@ -9,7 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 x = torch.randn(B, 90, C, device="cuda")
 w = torch.randn(C, C, 3, 3, device="cuda") * (2.0 / (9 * C)) ** 0.5
-u = hip.wino_transform_weights(w)
+CB = int(os.environ.get('XQ_CONV_BLOCK', '64'))
+u = hip.wino_transform_weights(w, CB)
 bias = torch.randn(C, device="cuda")
 res = torch.randn(B, 90, C, device="cuda")
 y = torch.empty_like(x)
@@ -18,7 +19,7 @@ FLAGS = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 
 def run():
     hip.check(hip.lib().xq_wino_conv3x3(x.data_ptr(), u.data_ptr(), bias.data_ptr(), res.data_ptr(), y.data_ptr(), B, C,
-                                        FLAGS, hip.stream_ptr(x.device)), "conv")
+                                        FLAGS | (4 if CB == 128 else 0), hip.stream_ptr(x.device)), "conv")
 
 
 for _ in range(3):

@@ -43,7 +43,7 @@ def test_winograd_conv_kernel_at_bench_sizes(c, b):
     w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).cuda()
     bias = (torch.randn(c, generator=g) * 0.1).cuda()
     res = torch.randn(b, 90, c, generator=g).cuda()
-    u = hip.wino_transform_weights(w)
+    u = hip.wino_transform_weights(w, 128 if c % 128 == 0 else 64)         # the variant the evaluator uses at this width
     ref = _f64_conv_nhwc(x, w, bias)
     for residual, relu in ((None, True), (res, True)):
         out = torch.full_like(x, float("nan"))

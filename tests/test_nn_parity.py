@@ -188,17 +188,22 @@ def test_winograd_conv_kernel_vs_torch(c, b):
     w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).cuda()
     bias = torch.randn(c, generator=g).cuda() * 0.1
     res = torch.randn(b, 90, c, generator=g).cuda()
-    u = hip.wino_transform_weights(w)
     x_nchw = x.view(b, 10, 9, c).permute(0, 3, 1, 2)
     ref = F.conv2d(x_nchw.double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(b, 90, c)
-    for residual, relu in ((None, True), (res, True), (res, False)):
-        want = ref + (0 if residual is None else residual.double())
-        want = torch.relu(want) if relu else want
-        out = torch.full_like(x, float("nan"))
-        hip.wino_conv3x3(x, u, bias, out, residual, relu)
-        torch.cuda.synchronize()
-        err = (out.double() - want).abs().max().item()
-        assert err < 4e-5, (c, b, relu, err)
+    outs = []
+    for co_block in ([64, 128] if c % 128 == 0 else [64]):    # narrow kernel (64 channels per workgroup) and XQ_CONV_WIDE
+        u = hip.wino_transform_weights(w, co_block)
+        for residual, relu in ((None, True), (res, True), (res, False)):
+            want = ref + (0 if residual is None else residual.double())
+            want = torch.relu(want) if relu else want
+            out = torch.full_like(x, float("nan"))
+            hip.wino_conv3x3(x, u, bias, out, residual, relu)
+            torch.cuda.synchronize()
+            err = (out.double() - want).abs().max().item()
+            assert err < 4e-5, (c, b, co_block, relu, err)
+        outs.append(out)
+    if len(outs) == 2:
+        assert torch.equal(outs[0], outs[1])                  # same arithmetic per output element in both variants
     with pytest.raises(hip.XqError):
         hip.wino_conv3x3(x, u, bias, x, None, True)          # in place is refused
 

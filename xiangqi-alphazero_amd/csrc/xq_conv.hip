@@ -60,10 +60,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NCO = 64;
+constexpr int NCO = 64;                             // output channels per workgroup of the narrow variant (NT = 2)
 constexpr int KC = 8;
 constexpr int TILES = 32;                           // tiles per workgroup (2.13 boards)
-constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;      // one 8-channel chunk of weights for 64 output channels: 40 KB
+constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;      // one 8-channel chunk of weights for 64 output channels: 40 KB (NT = 2)
 // Staged raw input of one 8-channel chunk: two planes (channel quad h = 0, 1) of 16-byte units, one unit per halo'd
 // board position.  Unit of position (board b, halo'd row y' = y + 1 in 0..11, halo'd column x' = x + 1 in 0..10):
 //     b * XU_B + (y' >> 1) * XU_PAIR + (y' & 1) * XU_ODD + x'
@@ -148,11 +148,19 @@ __device__ __forceinline__ f32x4 pk_fms4(f32x4 x, f32x2 c, f32x4 y) {
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
-__global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ X, const float *__restrict__ Ug,
+// NT = N-tiles (32 output channels each) per wave.  NT = 2: 64 output channels per workgroup, 160 accumulators per wave,
+// two workgroups per CU (the round-1 shape).  NT = 4 ("wide"): 128 output channels per workgroup, 320 accumulators per
+// wave (VGPRs + AGPRs of the unified 512-entry file), ONE workgroup per CU: every staged input chunk and every transformed
+// A operand feeds twice as many MFMAs, and the input is fetched by half as many workgroups.
+template <int NT>
+__global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float *__restrict__ X, const float *__restrict__ Ug,
                                                    const float *__restrict__ bias, const float *__restrict__ R,
                                                    float *__restrict__ Y, int B, int C, int flags, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Xr = lds;
+    constexpr int NCO = 32 * NT;                      // output channels per workgroup
+    constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;    // one 8-channel chunk of weights for them
+    constexpr int NF = 5 * NT, POOL = NF / 2;         // weight fragments per chunk; fragment registers (half a chunk ahead)
 
     const int tid = threadIdx.x, lane = tid & 63, wp = tid >> 6;
     const int NG = C / NCO;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     // B fragment (q, nt): lane (h, n) needs U[5 wp + q][8 chunk + 4h + j][64 cog + 32 nt + n], j = 0..3
     const unsigned ul = ((wp * 5 * 2 + h) * NCO + l31) * 16;
 
-    f32x16 acc[5][2];                                 // first written by chunk 0 (its MFMAs start from a zero C operand)
+    f32x16 acc[5][NT];                                // first written by chunk 0 (its MFMAs start from a zero C operand)
 
     f32x4 xreg[2];
     auto load_x = [&](int chunk) __attribute__((always_inline)) {
@@ -228,12 +236,12 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     };
     auto rowpair = [&](f32x4 d1, f32x4 d2) __attribute__((always_inline)) { return pk_fma4(d2, sgn, d1); };
 
-    f32x4 a[5], ub[5];
+    f32x4 a[5], ub[POOL];
     auto loop_barrier = [&]() __attribute__((always_inline)) { if (!(XQ_ABL & 16)) __syncthreads(); };
     // weight fragment f of a chunk: (q, nt) = (QO[f >> 1], f & 1), processing order of the column frequencies 1,2,3,0,4
     auto load_frag = [&](int chunk, int f, int slot) __attribute__((always_inline)) {
-        const int q = (f >> 1) == 0 ? 1 : (f >> 1) == 1 ? 2 : (f >> 1) == 2 ? 3 : (f >> 1) == 3 ? 0 : 4;
-        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f & 1) * (32 * 16));
+        const int q = (f / NT) == 0 ? 1 : (f / NT) == 1 ? 2 : (f / NT) == 2 ? 3 : (f / NT) == 3 ? 0 : 4;
+        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f % NT) * (32 * 16));
     };
     auto transform0 = [&]() __attribute__((always_inline)) {
         f32x4 w[5];
@@ -252,15 +260,15 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
         constexpr bool FIRST = decltype(first_tag)::value;
         f32x4 d1, d2, w1, w3, w2, w0, t, e, fm, v0;
 #pragma unroll
-        for (int f = 0; f < 10; ++f) {
-            const int g = f >> 1, nt = f & 1;
+        for (int f = 0; f < NF; ++f) {
+            const int g = f / NT, nt = f % NT;
             const int q = g == 0 ? 1 : g == 1 ? 2 : g == 2 ? 3 : g == 3 ? 0 : 4;
             const int col = g == 0 ? 1 : g == 1 ? 3 : g == 2 ? 2 : g == 3 ? 0 : 4;
-            const int slot = f % 5;
+            const int slot = f % POOL;
             if (nt == 0 && !(XQ_ABL & 2)) { d1 = ld4(Xr + tb1 + XO + col * XSTRIDE); d2 = ld4(Xr + tb2 + XO + col * XSTRIDE); }
             if (!(XQ_ABL & 6)) {
-                if (f == 6) a[3] = t;                                 // column frequency 3 retired with fragment 5
-                if (f == 8) a[0] = v0;
+                if (f == 3 * NT) a[3] = t;                            // column frequency 3 retired with the last fragment of group 2
+                if (f == 4 * NT) a[0] = v0;
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -270,19 +278,24 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
                 } else if (FIRST && jj == 0) {
                     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], zero, 0, 0, 0);
+                } else if (NT == 4 && nt == 3) {
+                    // wide variant: 20 accumulator tiles do not fit the 256 AGPRs; the compiler would spill four of them
+                    // around the loop.  The five tiles of the last N-tile are pinned to VGPRs ("+v"), the other 15 stay in
+                    // AGPRs.  (A dependent MFMA on its own vDst/SrcC needs no software wait states.)
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[q][jj]), "v"(ub[slot][jj]));
                 } else {
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], acc[q][nt], 0, 0, 0);
                 }
                 if (jj == 1) __builtin_amdgcn_sched_barrier(0);
             }
-            // weights: fragment f+5 replaces this one (f < 5: later in this chunk, else the next chunk's f-5)
-            if (!(XQ_ABL & 1)) { if (f < 5) load_frag(lchunk, f + 5, slot); else load_frag(nchunk_u, f - 5, slot); }
-            if (nt == 1 && (XQ_ABL & 4)) {                             // ablation: reads stay live, no arithmetic
+            // weights: fragment f+POOL replaces this one (f < POOL: later in this chunk, else the next chunk's f-POOL)
+            if (!(XQ_ABL & 1)) { if (f < POOL) load_frag(lchunk, f + POOL, slot); else load_frag(nchunk_u, f - POOL, slot); }
+            if (nt == NT - 1 && (XQ_ABL & 4)) {                        // ablation: reads stay live, no arithmetic
                 asm volatile("" ::"v"(d1), "v"(d2));
                 if (g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
             }
-            if (nt == 1 && (XQ_ABL & 2) && g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
-            if (nt == 1 && !(XQ_ABL & 6)) {
+            if (nt == NT - 1 && (XQ_ABL & 2) && g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
+            if (nt == NT - 1 && !(XQ_ABL & 6)) {
                 if (g == 0) {
                     w1 = rowpair(d1, d2);
                     if ((XQ_ABL & 512) && stage >= 0) { store_x(stage); load_x(stage + 1); }
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
 
     // ---- prologue ------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int f = 0; f < 5; ++f) load_frag(0, f, f);
+    for (int f = 0; f < POOL; ++f) load_frag(0, f, f);
     {
         f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int o = tid * 16; o < 2 * XRAW; o += 256 * 16) *(f32x4 *)(Xr + o) = z;
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     }
     if (XQ_ABL & 32) {                                 // ablation: no epilogue (keep the accumulators observable)
         float sacc = 0.0f;
-        for (int q = 0; q < 5; ++q) for (int n = 0; n < 2; ++n) for (int e = 0; e < 16; ++e) sacc += acc[q][n][e];
+        for (int q = 0; q < 5; ++q) for (int n = 0; n < NT; ++n) for (int e = 0; e < 16; ++e) sacc += acc[q][n][e];
         if (sacc == 1234.5f) Y[tid] = sacc;
         return;
     }
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
     float *ew = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;        // + compile-time offsets: immediates of the LDS ops
     const float *er = E + etile * ESTR + co;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NT; ++n) {
         // column half of the inverse transform on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3,
         // y2 = m1+m2+4 m3+m4
 #pragma unroll
@@ -397,13 +410,13 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv(const float *__restrict__ 
 #pragma unroll
             for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
         }
-        if (n == 0) {
+        if (n + 1 < NT) {
             if (has_r && eok) {
 #pragma unroll
-                for (int it = 0; it < 6; ++it)        // residual of the second half: in flight during its exchange
-                    resv[it] = ld4_r(R + obase + 32 + ((it / 3) * 9 + it % 3) * C);
+                for (int it = 0; it < 6; ++it)        // residual of the next 32 channels: in flight during their exchange
+                    resv[it] = ld4_r(R + obase + 32 * (n + 1) + ((it / 3) * 9 + it % 3) * C);
             }
-            __syncthreads();                          // the second half overwrites the planes
+            __syncthreads();                          // the next 32 channels overwrite the planes
         }
     }
 }
@@ -418,20 +431,28 @@ size_t xq_wino_weight_bytes(int channels) { return (size_t)20 * channels * chann
 int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bias, const float *dev_residual, float *dev_y,
                       int batch, int channels, int flags, void *stream) {
     if (!dev_x || !dev_u || !dev_bias || !dev_y || batch <= 0) return XQ_ERR_ARG;
-    if (channels < 64 || channels % 64 || 8 % (channels / 64)) return XQ_ERR_ARG;
+    const bool wide = (flags & XQ_CONV_WIDE) != 0;
+    const int nco = wide ? 128 : 64;
+    if (channels < nco || channels % nco || 8 % (channels / nco)) return XQ_ERR_ARG;
     if (dev_x == dev_y || dev_residual == dev_y) return XQ_ERR_ARG;
     if (((uintptr_t)dev_x | (uintptr_t)dev_u | (uintptr_t)dev_bias | (uintptr_t)dev_residual | (uintptr_t)dev_y) & 15) return XQ_ERR_ARG;
     if ((unsigned long long)batch * 90ull * (unsigned)channels * 4ull >= (1ull << 32)) return XQ_ERR_ARG;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         attr_set = true;
     }
     const int n_groups = (batch * 15 + TILES - 1) / TILES;
-    const int per = 8 / (channels / NCO);
+    const int lds_bytes = (XQ_ABL & 65536) ? 100 * 1024 : LDS_BYTES;      // ablation: one workgroup per CU
+    const int per = 8 / (channels / nco);
     const int rows = (n_groups + per - 1) / per;
-    hipLaunchKernelGGL(k_wino_conv, dim3(rows * 8), dim3(256), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
-                       dev_residual, dev_y, batch, channels, flags, n_groups);
+    if (wide)
+        hipLaunchKernelGGL(k_wino_conv<4>, dim3(rows * 8), dim3(256), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+                           dev_residual, dev_y, batch, channels, flags, n_groups);
+    else
+        hipLaunchKernelGGL(k_wino_conv<2>, dim3(rows * 8), dim3(256), lds_bytes, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+                           dev_residual, dev_y, batch, channels, flags, n_groups);
     return xq::launch_status();
 }
 

@@ -254,20 +254,20 @@ def heads_1x1(rows: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
     return p, v
 
 
-def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:
+def wino_transform_weights(w: torch.Tensor, co_block: int = 64) -> torch.Tensor:
     """Folded 3x3 filters float32[C,C,3,3] -> the kernel's pre-transformed layout (see include/xq_hip.h,
     xq_wino_conv3x3): U = s_p (G_r g G_c'^T)[p][j] per (co, ci) for the F(2,3) x F(3,3) transform, computed in float64,
-    stored float32 [C/64][C/8][20][2][64][4]."""
+    stored float32 [C/co_block][C/8][20][2][co_block][4]; co_block = 64 (narrow kernel) or 128 (XQ_CONV_WIDE)."""
     c = w.shape[0]
-    if w.shape != (c, c, 3, 3) or c % 64 or 8 % (c // 64):
-        raise XqError("wino_transform_weights: [C,C,3,3] with C in {64,128,256,512} required")
+    if w.shape != (c, c, 3, 3) or co_block not in (64, 128) or c % co_block or 8 % (c // co_block):
+        raise XqError("wino_transform_weights: [C,C,3,3] with C a multiple of co_block (64 or 128), C / co_block in {1,2,4,8}")
     gr = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
     # F(3,3) at the points 0, 1, -1, 2, inf; the kernel's B^T rows are the textbook ones times (2, 2, 6, 6, 1)
     gc = torch.tensor([[1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 2.0, 4.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
     gc = gc * torch.tensor([0.5, 0.5, 1.0 / 6.0, 1.0 / 6.0, 1.0], dtype=torch.float64)[:, None]
     u = torch.einsum("pr,oirs,qs->pqoi", gr, w.detach().to("cpu", torch.float64), gc)      # [4,5,co,ci]
     u[2] = -u[2]                    # the kernel forms row 2 of B_r^T d as d1 - d2 (the negative of the textbook row)
-    u = u.reshape(20, c // 64, 64, c // 8, 2, 4)                                           # xi, cog, co, chunk, quad, k
+    u = u.reshape(20, c // co_block, co_block, c // 8, 2, 4)                               # xi, cog, co, chunk, quad, k
     u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, k
     return u.to(w.device)
 
@@ -275,13 +275,15 @@ def wino_transform_weights(w: torch.Tensor) -> torch.Tensor:
 def wino_conv3x3(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, residual=None,
                  relu: bool = True, reverse: bool = False) -> torch.Tensor:
     """x, out, residual: float32[B, 90, C] contiguous (NHWC); out must not alias x / residual.  `reverse` walks the batch
-    back to front (identical results; see XQ_CONV_REVERSE)."""
+    back to front (identical results; see XQ_CONV_REVERSE).  The kernel variant follows the weight layout: `u` from
+    `wino_transform_weights(w, 128)` (shape [C/128, ...]) selects XQ_CONV_WIDE."""
     b, n, c = x.shape
     if n != 90 or not x.is_contiguous() or not out.is_contiguous() or out.shape != x.shape:
         raise XqError("wino_conv3x3: float32[B,90,C] contiguous tensors required")
     check(lib().xq_wino_conv3x3(x.data_ptr(), u.data_ptr(), bias.data_ptr(),
                                 None if residual is None else residual.data_ptr(), out.data_ptr(), b, c,
-                                int(relu) | (2 if reverse else 0), stream_ptr(x.device)), "xq_wino_conv3x3")
+                                int(relu) | (2 if reverse else 0) | (4 if u.shape[4] == 128 else 0), stream_ptr(x.device)),
+          "xq_wino_conv3x3")
     return out
 
 

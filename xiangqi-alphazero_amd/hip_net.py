@@ -42,6 +42,11 @@ class HipResNetEvaluator:
         self._legal = None           # evaluate_legal: persistent [B, 128] legal-move logits
         # XQ_CONV_REVERSE on every other conv launch (Infinity Cache reuse between layers); XQ_CONV_ALTERNATE=0 for A/B runs
         self.alternate_order = os.environ.get("XQ_CONV_ALTERNATE", "1") != "0"
+        # conv kernel variant: 128 output channels per workgroup (XQ_CONV_WIDE) where the width allows, else 64
+        want = os.environ.get("XQ_CONV_BLOCK", "")
+        self.co_block = int(want) if want in ("64", "128") else (128 if self.C % 128 == 0 else 64)
+        if self.C % self.co_block:
+            self.co_block = 64
         self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []
@@ -55,10 +60,11 @@ class HipResNetEvaluator:
         new = {}
         new["wt_in"] = hip.stem_weights(ref.w_in)                    # [135, C] for xq_stem_conv
         new["b_in"] = ref.b_in
+        cb = self.co_block
         for i in range(self.num_res_blocks):
-            new[f"u1_{i}"] = hip.wino_transform_weights(getattr(ref, f"w1_{i}"))
+            new[f"u1_{i}"] = hip.wino_transform_weights(getattr(ref, f"w1_{i}"), cb)
             new[f"b1_{i}"] = getattr(ref, f"b1_{i}")
-            new[f"u2_{i}"] = hip.wino_transform_weights(getattr(ref, f"w2_{i}"))
+            new[f"u2_{i}"] = hip.wino_transform_weights(getattr(ref, f"w2_{i}"), cb)
             new[f"b2_{i}"] = getattr(ref, f"b2_{i}")
         # both heads' 1x1 convolutions as one [36, C] matrix: rows 0-31 policy, 32-35 value (xq_heads_1x1)
         new["w_pv"] = torch.cat([ref.w_p.view(ref.w_p.shape[0], -1), ref.w_v.view(ref.w_v.shape[0], -1)], 0)
