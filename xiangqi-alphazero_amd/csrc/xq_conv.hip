@@ -79,7 +79,6 @@ constexpr int ESTR = 36;                             // floats per tile row of a
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
-constexpr int LDS_BYTES_WIDE = 2 * XRAW + 2 * E_BYTES;           // persistent variant: staging + two exchange sets
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -159,63 +158,55 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     char *Xr = lds;
     constexpr int NCO = 32 * NT;                      // output channels per workgroup
     constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;    // one 8-channel chunk of weights for them
-#ifndef XQ_WIDE_POOL
-#define XQ_WIDE_POOL 10
-#endif
-    constexpr int NF = 5 * NT;                        // weight fragments per chunk
-    constexpr int POOL = NT == 2 ? 5 : XQ_WIDE_POOL;  // fragment registers: half a chunk ahead (or, wide, a whole chunk: 20)
+    constexpr int NF = 5 * NT, POOL = NF / 2;         // weight fragments per chunk; fragment registers (half a chunk ahead)
 
-    // The wide variant is PERSISTENT: the grid is one workgroup per CU and each workgroup walks its share of the tile
-    // groups; the first loads of the next group (weight fragments, two input chunks) are issued before the epilogue of the
-    // current one, so their latency and the launch of a new workgroup never sit between two main loops, and the LDS
-    // exchange planes of the epilogue live beside the staging buffers (zero halo written once).
-    constexpr bool PERSIST = NT == 4;
     const int tid = threadIdx.x, lane = tid & 63, wp = tid >> 6;
     const int NG = C / NCO;
     const int per = 8 / NG;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     // ablation 2048 (C = 256): two weight slices per XCD, the two blocks that share a tile group back to back on it
     const int cog = (XQ_ABL & 2048) ? 2 * (xcd & 1) + (rr & 1) : xcd % NG;
-    const int rr_step = PERSIST ? (int)(gridDim.x >> 3) : 0x40000000;
     // flags bit 1: walk the batch back to front.  A launch that reads what the previous launch wrote (the next layer of
     // the tower) then starts with the boards written last -- still in the 256 MB Infinity Cache -- instead of the oldest.
-    auto group_of = [&](int r) __attribute__((always_inline)) {
-        return (XQ_ABL & 2048) ? (r >> 1) * 4 + (xcd >> 1) : r * per + xcd / NG;
-    };
-    if (group_of(rr) >= n_groups) return;
+    const int tg_fwd = (XQ_ABL & 2048) ? (rr >> 1) * 4 + (xcd >> 1) : rr * per + xcd / NG;
+    const int tg = (flags & 2) ? n_groups - 1 - tg_fwd : tg_fwd;
+    if (tg_fwd >= n_groups) return;
     const int relu = flags & 1;
     const int T = B * 15;
+    const int t0 = tg * TILES;
+    const int b_lo = t0 / 15;
     const int NCH = C / KC;
     const int h = lane >> 5, l31 = lane & 31;
+
+    // transform / MFMA role: tile l31, channel quad h, Winograd row wp
+    const int gt = t0 + l31 < T ? t0 + l31 : T - 1;
+    const int tb = gt / 15, tt = gt - tb * 15, ty = tt / 3, tx = tt - ty * 3;
+    const int tbase = ((tb - b_lo) * XU_B + ty * XU_PAIR + 3 * tx) * XSTRIDE + h * XPLANE;   // P(tb, 2ty-1, 3tx-1)
+    const int tb1 = tbase + (wp == 0 ? 0 : XU_ODD) * XSTRIDE;                                 // patch row 0 or 1
+    const int tb2 = tbase + (wp == 3 ? XU_PAIR + XU_ODD : XU_PAIR) * XSTRIDE;                 // patch row 2 or 3
     const float sg = wp == 1 ? 1.0f : -1.0f;
     const f32x2 sgn = {sg, sg};
     const f32x2 two = {2.0f, 2.0f}, three = {3.0f, 3.0f}, mtwo = {-2.0f, -2.0f}, four = {4.0f, 4.0f};
-    const int spart = tid & 1;
 
     // staging role: a contiguous run of positions (first tile's halo row .. last tile's), 2 x 16 B per position and chunk
+    const int tl = (t0 + TILES - 1 < T ? t0 + TILES - 1 : T - 1);
+    const int b_hi = tl / 15;
+    const int y_min = 2 * ((t0 - b_lo * 15) / 3) - 1, y_max = 2 * ((tl - b_hi * 15) / 3) + 2;
+    const int pos_first = (y_min > 0 ? y_min : 0) * 9;
+    const int pos_last = (b_hi - b_lo) * 90 + ((y_max < 9 ? y_max : 9) + 1) * 9 - 1;
+    const int spos = pos_first + (tid >> 1), spart = tid & 1;
+    const unsigned xgo = (unsigned)(((long long)b_lo * 90 + spos) * C + spart * 4) * 4u;
+    const unsigned xstep = 128u * (unsigned)C * 4u;
     unsigned xgk[2];
     int xl[2];
-    auto staging_of = [&](int tg) __attribute__((always_inline)) {
-        const int t0 = tg * TILES, b_lo = t0 / 15;
-        const int tl = (t0 + TILES - 1 < T ? t0 + TILES - 1 : T - 1);
-        const int b_hi = tl / 15;
-        const int y_min = 2 * ((t0 - b_lo * 15) / 3) - 1, y_max = 2 * ((tl - b_hi * 15) / 3) + 2;
-        const int pos_first = (y_min > 0 ? y_min : 0) * 9;
-        const int pos_last = (b_hi - b_lo) * 90 + ((y_max < 9 ? y_max : 9) + 1) * 9 - 1;
-        const int spos = pos_first + (tid >> 1);
-        const unsigned xgo = (unsigned)(((long long)b_lo * 90 + spos) * C + spart * 4) * 4u;
-        const unsigned xstep = 128u * (unsigned)C * 4u;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pos = spos + 128 * k;
-            const int bi = pos / 90, rem = pos - bi * 90, y = rem / 9, x = rem - y * 9;
-            const bool ok = pos <= pos_last;
-            xgk[k] = ok ? xgo + k * xstep : 0xFFFFFFF0u;
-            xl[k] = (ok ? bi * XU_B + ((y + 1) >> 1) * XU_PAIR + ((y + 1) & 1) * XU_ODD + x + 1 : XDUMP) * XSTRIDE + spart * XPLANE;
-        }
-    };
-    const int tg_first = (flags & 2) ? n_groups - 1 - group_of(rr) : group_of(rr);
-    staging_of(tg_first);
+    for (int k = 0; k < 2; ++k) {
+        const int pos = spos + 128 * k;
+        const int bi = pos / 90, rem = pos - bi * 90, y = rem / 9, x = rem - y * 9;
+        const bool ok = pos <= pos_last;
+        xgk[k] = ok ? xgo + k * xstep : 0xFFFFFFF0u;
+        xl[k] = (ok ? bi * XU_B + ((y + 1) >> 1) * XU_PAIR + ((y + 1) & 1) * XU_ODD + x + 1 : XDUMP) * XSTRIDE + spart * XPLANE;
+    }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((unsigned)B * 90u * (unsigned)C * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)(Ug + (size_t)cog * NCH * (UBUF_BYTES / 4)), 0,
                                                                          NCH * UBUF_BYTES, 0x00020000);
@@ -223,13 +214,14 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     const unsigned ul = ((wp * 5 * 2 + h) * NCO + l31) * 16;
 
     f32x16 acc[5][NT];                                // first written by chunk 0 (its MFMAs start from a zero C operand)
-    int tb1 = 0, tb2 = 0;                             // transform / MFMA role of this lane in the current group (set per group)
 
     f32x4 xreg[2];
     auto load_x = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (XQ_ABL & (128 | 256))       // ablation: every workgroup reads the same 256 KB (L2-resident): latency without HBM
+            if (XQ_ABL & 128)            // ablation: same bytes per chunk, but one contiguous 8 KB run per workgroup (coalesced)
+                xreg[k] = buf_ld4(xrs, (unsigned)b_lo * 90u * (unsigned)C * 4u + (unsigned)(tid + 256 * k) * 16u, chunk * 8192);
+            else if (XQ_ABL & 256)       // ablation: every workgroup reads the same 256 KB (L2-resident): latency without HBM
                 xreg[k] = buf_ld4(xrs, (unsigned)(tid + 256 * k) * 16u, chunk * 8192);
             else
                 xreg[k] = buf_ld4(xrs, xgk[k], chunk * 32);
@@ -295,7 +287,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
                 if (jj == 1) __builtin_amdgcn_sched_barrier(0);
             }
             // weights: fragment f+POOL replaces this one (f < POOL: later in this chunk, else the next chunk's f-POOL)
-            if (!(XQ_ABL & 1)) { if (f + POOL < NF) load_frag(lchunk, f + POOL, slot); else load_frag(nchunk_u, f + POOL - NF, slot); }
+            if (!(XQ_ABL & 1)) { if (f < POOL) load_frag(lchunk, f + POOL, slot); else load_frag(nchunk_u, f - POOL, slot); }
             if (nt == NT - 1 && (XQ_ABL & 4)) {                        // ablation: reads stay live, no arithmetic
                 asm volatile("" ::"v"(d1), "v"(d2));
                 if (g == 3 && stage >= 0 && !(XQ_ABL & 8)) { store_x(stage); load_x(stage + 1); }
@@ -318,7 +310,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         }
     };
 
-    // ---- prologue of the first group ---------------------------------------------------------------------------
+    // ---- prologue ------------------------------------------------------------------------------------------
 #pragma unroll
     for (int f = 0; f < POOL; ++f) load_frag(0, f, f);
     {
@@ -330,18 +322,6 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
 #pragma unroll
     for (int k = 0; k < 2; ++k) x1[k] = buf_ld4(xrs, xgk[k], 32);
     __syncthreads();                                  // zero fill before the first stores
-
-    for (int r = rr;; r += rr_step) {
-    const int tg = (flags & 2) ? n_groups - 1 - group_of(r) : group_of(r);
-    const int t0 = tg * TILES;
-    const int b_lo = t0 / 15;
-    {   // transform / MFMA role: tile l31, channel quad h, Winograd row wp
-        const int gt = t0 + l31 < T ? t0 + l31 : T - 1;
-        const int tb = gt / 15, tt = gt - tb * 15, ty = tt / 3, tx = tt - ty * 3;
-        const int tbase = ((tb - b_lo) * XU_B + ty * XU_PAIR + 3 * tx) * XSTRIDE + h * XPLANE;   // P(tb, 2ty-1, 3tx-1)
-        tb1 = tbase + (wp == 0 ? 0 : XU_ODD) * XSTRIDE;                                           // patch row 0 or 1
-        tb2 = tbase + (wp == 3 ? XU_PAIR + XU_ODD : XU_PAIR) * XSTRIDE;                           // patch row 2 or 3
-    }
     store_x(0);
 #pragma unroll
     for (int k = 0; k < 2; ++k) *(f32x4 *)(Xr + XRAW + xl[k]) = x1[k];
@@ -361,14 +341,6 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         loop_barrier();
         chunk_body(c + 2 < NCH ? c + 2 : c + 1, c + 1, std::integral_constant<int, 0>{}, c + 3, std::false_type{});
         loop_barrier();
-    }
-    // ---- the next group's first loads go out before this group's epilogue (persistent variant)
-    const bool has_next = PERSIST && group_of(r + rr_step) < n_groups;
-    if (has_next) {                                    // input chunks 0 and 1 now; the weight fragments once the epilogue has
-        staging_of((flags & 2) ? n_groups - 1 - group_of(r + rr_step) : group_of(r + rr_step));     // freed registers
-        load_x(0);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) x1[k] = buf_ld4(xrs, xgk[k], 32);
     }
     if (XQ_ABL & 32) {                                 // ablation: no epilogue (keep the accumulators observable)
         float sacc = 0.0f;
@@ -391,22 +363,13 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
         f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        resv[it] = (has_r && eok) ? ld4_r(R + obase + (PERSIST ? 32 * (NT - 1) : 0) + ((it / 3) * 9 + it % 3) * C) : z;
+        resv[it] = (has_r && eok) ? ld4_r(R + obase + ((it / 3) * 9 + it % 3) * C) : z;
     }
-    // exchange planes [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats.  Narrow variant: over the staging buffers
-    // (dead by now), one set, two barriers per round.  Persistent variant: two sets beside the staging buffers, used
-    // alternately -- a round's planes are rewritten two rounds later, behind the barrier of the round in between.
-    float *E = (float *)(lds + (PERSIST ? 2 * XRAW : 0));
-    float *ew0 = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;       // + compile-time offsets: immediates of the LDS ops
-    const float *er0 = E + etile * ESTR + co;
-    // round order: the persistent variant drains its VGPR-resident tiles (N-tile 3) first; the registers they free take
-    // the next group's first weight fragments while the other three rounds run
+    float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats
+    float *ew = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;        // + compile-time offsets: immediates of the LDS ops
+    const float *er = E + etile * ESTR + co;
 #pragma unroll
-    for (int rnd = 0; rnd < NT; ++rnd) {
-        const int n = PERSIST ? (rnd + NT - 1) % NT : rnd;
-        const int n_next = PERSIST ? (rnd + NT) % NT : rnd + 1;
-        float *ew = ew0 + (PERSIST ? (rnd & 1) * (E_BYTES / 4) : 0);
-        const float *er = er0 + (PERSIST ? (rnd & 1) * (E_BYTES / 4) : 0);
+    for (int n = 0; n < NT; ++n) {
         // column half of the inverse transform on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3,
         // y2 = m1+m2+4 m3+m4
 #pragma unroll
@@ -445,21 +408,15 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
 #pragma unroll
             for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
         }
-        if (rnd + 1 < NT) {
+        if (n + 1 < NT) {
             if (has_r && eok) {
 #pragma unroll
                 for (int it = 0; it < 6; ++it)        // residual of the next 32 channels: in flight during their exchange
-                    resv[it] = ld4_r(R + obase + 32 * n_next + ((it / 3) * 9 + it % 3) * C);
+                    resv[it] = ld4_r(R + obase + 32 * (n + 1) + ((it / 3) * 9 + it % 3) * C);
             }
-            if (!PERSIST) __syncthreads();            // the next 32 channels overwrite the planes
-        }
-        if (PERSIST && rnd == 0 && has_next) {
-#pragma unroll
-            for (int f = 0; f < POOL; ++f) load_frag(0, f, f);
+            __syncthreads();                          // the next 32 channels overwrite the planes
         }
     }
-    if (!has_next) break;
-    }   // next tile group of this workgroup
 }
 
 }  // namespace
@@ -481,18 +438,17 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     static thread_local bool attr_set = false;
     if (!attr_set) {
         XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_WIDE));
+        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         attr_set = true;
     }
     const int n_groups = (batch * 15 + TILES - 1) / TILES;
     const int lds_bytes = (XQ_ABL & 65536) ? 100 * 1024 : LDS_BYTES;      // ablation: one workgroup per CU
     const int per = 8 / (channels / nco);
     const int rows = (n_groups + per - 1) / per;
-    if (wide) {      // persistent: one workgroup per CU (256 CUs = 32 per XCD), fewer when the launch has fewer groups
-        int prows = rows < 32 ? rows : 32;
-        hipLaunchKernelGGL(k_wino_conv<4>, dim3(prows * 8), dim3(256), LDS_BYTES_WIDE, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+    if (wide)
+        hipLaunchKernelGGL(k_wino_conv<4>, dim3(rows * 8), dim3(256), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
-    } else
+    else
         hipLaunchKernelGGL(k_wino_conv<2>, dim3(rows * 8), dim3(256), lds_bytes, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
     return xq::launch_status();
