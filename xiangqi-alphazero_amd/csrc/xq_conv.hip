@@ -79,6 +79,7 @@ constexpr int ESTR = 36;                             // floats per tile row of a
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
+constexpr int LDS_BYTES_WIDE = 2 * XRAW > 2 * E_BYTES ? 2 * XRAW : 2 * E_BYTES;     // two exchange sets
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -359,17 +360,28 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     const int ebd = eg / 15, et2 = eg - ebd * 15, ety = et2 / 3, etx = et2 - ety * 3;
     const size_t obase = eok ? ((size_t)ebd * 90 + (2 * ety) * 9 + 3 * etx) * C + cog * NCO + co : 0;
     const bool has_r = R != nullptr;
-    f32x4 resv[6];
+    // Residual loads run ahead of their use: the narrow variant (a co-resident workgroup covers the wait) one round, the wide
+    // variant (alone on its CU, every wait exposed) two rounds -- its first two sets go out here, before the exchange starts.
+    constexpr int RA = NT == 4 ? 2 : 1;               // rounds of residual prefetch
+    f32x4 resv[RA][6];
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
-        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        resv[it] = (has_r && eok) ? ld4_r(R + obase + ((it / 3) * 9 + it % 3) * C) : z;
-    }
-    float *E = (float *)lds;                          // [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats
-    float *ew = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;        // + compile-time offsets: immediates of the LDS ops
-    const float *er = E + etile * ESTR + co;
+    for (int s = 0; s < RA; ++s)
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            resv[s][it] = (has_r && eok) ? ld4_r(R + obase + 32 * s + ((it / 3) * 9 + it % 3) * C) : z;
+        }
+    // exchange planes [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats, over the staging buffers (dead by now).
+    // Wide variant: two sets used alternately (one workgroup per CU: the LDS is there) -- a set is rewritten two rounds
+    // later, behind the barrier of the round in between, so a round costs one barrier instead of two.
+    constexpr bool E2 = NT == 4;
+    float *E = (float *)lds;
+    float *ew0 = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;       // + compile-time offsets: immediates of the LDS ops
+    const float *er0 = E + etile * ESTR + co;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
+        float *ew = ew0 + (E2 ? (n & 1) * (E_BYTES / 4) : 0);
+        const float *er = er0 + (E2 ? (n & 1) * (E_BYTES / 4) : 0);
         // column half of the inverse transform on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3,
         // y2 = m1+m2+4 m3+m4
 #pragma unroll
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
             f32x4 y;
             if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
             else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
-            y = y + bv + resv[it];
+            y = y + bv + resv[n % RA][it];
             if (relu) { y.x = relu1(y.x); y.y = relu1(y.y); y.z = relu1(y.z); y.w = relu1(y.w); }
             yv[it] = y;
         }
@@ -408,14 +420,12 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
 #pragma unroll
             for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
         }
-        if (n + 1 < NT) {
-            if (has_r && eok) {
+        if (n + RA < NT && has_r && eok) {
 #pragma unroll
-                for (int it = 0; it < 6; ++it)        // residual of the next 32 channels: in flight during their exchange
-                    resv[it] = ld4_r(R + obase + 32 * (n + 1) + ((it / 3) * 9 + it % 3) * C);
-            }
-            __syncthreads();                          // the next 32 channels overwrite the planes
+            for (int it = 0; it < 6; ++it)            // residual of a later 32 channels: in flight during the rounds between
+                resv[n % RA][it] = ld4_r(R + obase + 32 * (n + RA) + ((it / 3) * 9 + it % 3) * C);
         }
+        if (n + 1 < NT && !E2) __syncthreads();       // the next 32 channels overwrite the planes
     }
 }
 
@@ -438,7 +448,7 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     static thread_local bool attr_set = false;
     if (!attr_set) {
         XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_WIDE));
         attr_set = true;
     }
     const int n_groups = (batch * 15 + TILES - 1) / TILES;
@@ -446,7 +456,7 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     const int per = 8 / (channels / nco);
     const int rows = (n_groups + per - 1) / per;
     if (wide)
-        hipLaunchKernelGGL(k_wino_conv<4>, dim3(rows * 8), dim3(256), LDS_BYTES, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+        hipLaunchKernelGGL(k_wino_conv<4>, dim3(rows * 8), dim3(256), LDS_BYTES_WIDE, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
     else
         hipLaunchKernelGGL(k_wino_conv<2>, dim3(rows * 8), dim3(256), lds_bytes, (hipStream_t)stream, dev_x, dev_u, dev_bias,
