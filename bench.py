@@ -183,7 +183,9 @@ def measure(args, dev, rank, world, dist, backend, peaked):
     s0 = eng.stats()
     import threading
     smi = {}
-    smi_thread = threading.Thread(target=smi_sample, args=(smi,)) if rank == 0 else None
+    # not under a profiler: its preloaded library has the GPU initialised in every child before that child execs rocm-smi
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    smi_thread = threading.Thread(target=smi_sample, args=(smi,)) if (rank == 0 and not profiled) else None
     graphed = bool(args.graph and sparse and eng.capture_step(warmup=0))
     if hasattr(ev, "timing") and not graphed:
         ev.timing = True            # HIP events around each launch of the dominant kernel, timed region only
