@@ -79,7 +79,7 @@ constexpr int ESTR = 36;                             // floats per tile row of a
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
-constexpr int LDS_BYTES_WIDE = 2 * XRAW > 2 * E_BYTES ? 2 * XRAW : 2 * E_BYTES;     // two exchange sets
+constexpr int LDS_BYTES_WIDE = 4 * 3 * TILES * (64 + 4) * 4;                        // exchange planes of a 64-channel round
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -360,72 +360,82 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     const int ebd = eg / 15, et2 = eg - ebd * 15, ety = et2 / 3, etx = et2 - ety * 3;
     const size_t obase = eok ? ((size_t)ebd * 90 + (2 * ety) * 9 + 3 * etx) * C + cog * NCO + co : 0;
     const bool has_r = R != nullptr;
-    // Residual loads run ahead of their use: the narrow variant (a co-resident workgroup covers the wait) one round, the wide
-    // variant (alone on its CU, every wait exposed) two rounds -- its first two sets go out here, before the exchange starts.
-    constexpr int RA = NT == 4 ? 2 : 1;               // rounds of residual prefetch
-    f32x4 resv[RA][6];
+    // The exchange runs in rounds of RW N-tiles (32 RW output channels): one round = column transform + LDS writes, ONE
+    // barrier, row transform + bias/residual/ReLU + stores by thread (tile, channel quad).  Narrow variant: RW = 1, planes
+    // over the staging buffers, a second barrier before they are rewritten.  Wide variant (alone on its CU: every
+    // dependent LDS round trip is exposed, and the LDS is all its own): RW = 2 -- two rounds instead of four
+    // (104 KB of planes).  Residual loads run one round ahead.
+    constexpr int RW = NT == 4 ? 2 : 1, ROUNDS = NT / RW;
+    constexpr int ESTR_R = 32 * RW + 4;               // floats per tile row of a plane
+    constexpr int ESET = 4 * 3 * TILES * ESTR_R;     // floats per plane set
+    constexpr bool E2 = false;                        // two 64-channel plane sets (209 KB) do not fit the CU's 160 KB
+    f32x4 resv[RW][6];
 #pragma unroll
-    for (int s = 0; s < RA; ++s)
+    for (int s = 0; s < RW; ++s)
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
             f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
             resv[s][it] = (has_r && eok) ? ld4_r(R + obase + 32 * s + ((it / 3) * 9 + it % 3) * C) : z;
         }
-    // exchange planes [4 rows p][3 b][32 tiles][32 co], tile stride ESTR floats, over the staging buffers (dead by now).
-    // Wide variant: two sets used alternately (one workgroup per CU: the LDS is there) -- a set is rewritten two rounds
-    // later, behind the barrier of the round in between, so a round costs one barrier instead of two.
-    constexpr bool E2 = NT == 4;
     float *E = (float *)lds;
-    float *ew0 = E + ((wp * 3) * TILES + 4 * h) * ESTR + l31;       // + compile-time offsets: immediates of the LDS ops
-    const float *er0 = E + etile * ESTR + co;
+    float *ew0 = E + ((wp * 3) * TILES + 4 * h) * ESTR_R + l31;     // + compile-time offsets: immediates of the LDS ops
+    const float *er0 = E + etile * ESTR_R + co;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        float *ew = ew0 + (E2 ? (n & 1) * (E_BYTES / 4) : 0);
-        const float *er = er0 + (E2 ? (n & 1) * (E_BYTES / 4) : 0);
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        float *ew = ew0 + (E2 ? (rd & 1) * ESET : 0);
+        const float *er = er0 + (E2 ? (rd & 1) * ESET : 0);
         // column half of the inverse transform on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3,
         // y2 = m1+m2+4 m3+m4
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const f32x2 m0 = {acc[0][n][e], acc[0][n][e + 1]}, m1 = {acc[1][n][e], acc[1][n][e + 1]};
-            const f32x2 m2 = {acc[2][n][e], acc[2][n][e + 1]}, m3 = {acc[3][n][e], acc[3][n][e + 1]};
-            const f32x2 m4 = {acc[4][n][e], acc[4][n][e + 1]};
-            const f32x2 s12 = pk_add2(m1, m2);
-            const f32x2 y0 = pk_add2(pk_add2(m0, m3), s12);
-            const f32x2 y1 = pk_fma2(m3, two, pk_sub2(m1, m2));
-            const f32x2 y2 = pk_add2(pk_fma2(m3, four, s12), m4);
+        for (int s = 0; s < RW; ++s) {
+            const int n = rd * RW + s;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int tile = ((e + k) & 3) + 8 * ((e + k) >> 2);     // + 4 h (in ew)
-                ew[(0 * TILES + tile) * ESTR] = y0[k];
-                ew[(1 * TILES + tile) * ESTR] = y1[k];
-                ew[(2 * TILES + tile) * ESTR] = y2[k];
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 m0 = {acc[0][n][e], acc[0][n][e + 1]}, m1 = {acc[1][n][e], acc[1][n][e + 1]};
+                const f32x2 m2 = {acc[2][n][e], acc[2][n][e + 1]}, m3 = {acc[3][n][e], acc[3][n][e + 1]};
+                const f32x2 m4 = {acc[4][n][e], acc[4][n][e + 1]};
+                const f32x2 s12 = pk_add2(m1, m2);
+                const f32x2 y0 = pk_add2(pk_add2(m0, m3), s12);
+                const f32x2 y1 = pk_fma2(m3, two, pk_sub2(m1, m2));
+                const f32x2 y2 = pk_add2(pk_fma2(m3, four, s12), m4);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int tile = ((e + k) & 3) + 8 * ((e + k) >> 2);     // + 4 h (in ew)
+                    ew[(0 * TILES + tile) * ESTR_R + 32 * s] = y0[k];
+                    ew[(1 * TILES + tile) * ESTR_R + 32 * s] = y1[k];
+                    ew[(2 * TILES + tile) * ESTR_R + 32 * s] = y2[k];
+                }
             }
         }
         __syncthreads();
-        const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
-        f32x4 yv[6];
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int ya = it / 3, yb = it % 3;
-            const float *e0 = er + yb * TILES * ESTR;
-            const int pstride = 3 * TILES * ESTR;        // next Winograd row p
-            f32x4 y;
-            if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
-            else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
-            y = y + bv + resv[n % RA][it];
-            if (relu) { y.x = relu1(y.x); y.y = relu1(y.y); y.z = relu1(y.z); y.w = relu1(y.w); }
-            yv[it] = y;
-        }
-        if (eok) {
+        for (int s = 0; s < RW; ++s) {
+            const int n = rd * RW + s;
+            const f32x4 bv = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
+            f32x4 yv[6];
 #pragma unroll
-            for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
-        }
-        if (n + RA < NT && has_r && eok) {
+            for (int it = 0; it < 6; ++it) {
+                const int ya = it / 3, yb = it % 3;
+                const float *e0 = er + yb * TILES * ESTR_R + 32 * s;
+                const int pstride = 3 * TILES * ESTR_R;      // next Winograd row p
+                f32x4 y;
+                if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
+                else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
+                y = y + bv + resv[s][it];
+                if (relu) { y.x = relu1(y.x); y.y = relu1(y.y); y.z = relu1(y.z); y.w = relu1(y.w); }
+                yv[it] = y;
+            }
+            if (eok) {
 #pragma unroll
-            for (int it = 0; it < 6; ++it)            // residual of a later 32 channels: in flight during the rounds between
-                resv[n % RA][it] = ld4_r(R + obase + 32 * (n + RA) + ((it / 3) * 9 + it % 3) * C);
+                for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
+            }
+            if (rd + 1 < ROUNDS && has_r && eok) {
+#pragma unroll
+                for (int it = 0; it < 6; ++it)        // residual of the next round: in flight during its column transform
+                    resv[s][it] = ld4_r(R + obase + 32 * (n + RW) + ((it / 3) * 9 + it % 3) * C);
+            }
         }
-        if (n + 1 < NT && !E2) __syncthreads();       // the next 32 channels overwrite the planes
+        if (rd + 1 < ROUNDS && !E2) __syncthreads();  // the next round overwrites the planes
     }
 }
 
