@@ -43,10 +43,11 @@ class HipResNetEvaluator:
         # XQ_CONV_REVERSE on every other conv launch (Infinity Cache reuse between layers); XQ_CONV_ALTERNATE=0 for A/B runs
         self.alternate_order = os.environ.get("XQ_CONV_ALTERNATE", "1") != "0"
         # conv kernel variant: 128 output channels per workgroup (XQ_CONV_WIDE) where the width allows, else 64
-        want = os.environ.get("XQ_CONV_BLOCK", "")
-        self.co_block = int(want) if want in ("64", "128") else (128 if self.C % 128 == 0 else 64)
-        if self.C % self.co_block:
-            self.co_block = 64
+        want = os.environ.get("XQ_CONV_BLOCK", "")                 # "64" / "128": force one variant (A/B runs)
+        if want in ("64", "128") and self.C % int(want) == 0:
+            self.co_blocks = [int(want)]
+        else:
+            self.co_blocks = [64, 128] if self.C % 128 == 0 else [64]
         self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []
@@ -60,11 +61,11 @@ class HipResNetEvaluator:
         new = {}
         new["wt_in"] = hip.stem_weights(ref.w_in)                    # [135, C] for xq_stem_conv
         new["b_in"] = ref.b_in
-        cb = self.co_block
         for i in range(self.num_res_blocks):
-            new[f"u1_{i}"] = hip.wino_transform_weights(getattr(ref, f"w1_{i}"), cb)
+            for cb in self.co_blocks:                                # one pre-transformed copy per kernel variant in use
+                new[f"u1_{i}_{cb}"] = hip.wino_transform_weights(getattr(ref, f"w1_{i}"), cb)
+                new[f"u2_{i}_{cb}"] = hip.wino_transform_weights(getattr(ref, f"w2_{i}"), cb)
             new[f"b1_{i}"] = getattr(ref, f"b1_{i}")
-            new[f"u2_{i}"] = hip.wino_transform_weights(getattr(ref, f"w2_{i}"), cb)
             new[f"b2_{i}"] = getattr(ref, f"b2_{i}")
         # both heads' 1x1 convolutions as one [36, C] matrix: rows 0-31 policy, 32-35 value (xq_heads_1x1)
         new["w_pv"] = torch.cat([ref.w_p.view(ref.w_p.shape[0], -1), ref.w_v.view(ref.w_v.shape[0], -1)], 0)
@@ -85,8 +86,18 @@ class HipResNetEvaluator:
                 old.copy_(value)
             else:
                 setattr(self, name, value)
-        self.blocks = [(getattr(self, f"u1_{i}"), getattr(self, f"b1_{i}"), getattr(self, f"u2_{i}"), getattr(self, f"b2_{i}"))
-                       for i in range(self.num_res_blocks)]
+        self.blocks_by_variant = {cb: [(getattr(self, f"u1_{i}_{cb}"), getattr(self, f"b1_{i}"), getattr(self, f"u2_{i}_{cb}"),
+                                        getattr(self, f"b2_{i}")) for i in range(self.num_res_blocks)] for cb in self.co_blocks}
+        self.blocks = self.blocks_by_variant[self.co_blocks[-1]]
+
+    def _blocks_for(self, batch: int):
+        """Kernel variant by launch size: the wide one (128 output channels per workgroup, one workgroup per CU) pays once a
+        launch has at least ~4 rounds of 256 workgroups; smaller launches (BASELINE configs[1]: 1024 games x 128 channels = 480
+        wide workgroups) fill the chip better with the narrow one (64 channels, two workgroups per CU)."""
+        if 128 in self.blocks_by_variant and 64 in self.blocks_by_variant:
+            wide_groups = ((batch * 15 + 31) // 32) * (self.C // 128)
+            return self.blocks_by_variant[128 if wide_groups >= 1024 else 64]
+        return self.blocks
 
     def _buffers(self, b):
         """Four NHWC activation buffers, grown to the largest batch seen (callers with a varying batch -- the arena
@@ -117,7 +128,7 @@ class HipResNetEvaluator:
         h = hip.stem_conv(x.contiguous(), self.wt_in, self.b_in, t0)
         free = [t1, t2, t3]
         rev = self.alternate_order                                   # launches alternate front-to-back / back-to-front:
-        for u1, b1, u2, b2 in self.blocks:                           # each starts on what the previous one wrote last
+        for u1, b1, u2, b2 in self._blocks_for(b):                   # each starts on what the previous one wrote last
             y = next(t for t in free if t.data_ptr() != h.data_ptr())
             self._conv(h, u1, b1, y, None, rev)
             o = next(t for t in free if t.data_ptr() != h.data_ptr() and t.data_ptr() != y.data_ptr())
