@@ -164,14 +164,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     const int tid = threadIdx.x, lane = tid & 63, wp = tid >> 6;
     const int NG = C / NCO;
     const int per = 8 / NG;
-    const int xcd = blockIdx.x & 7;
-#ifdef XQ_PERSIST_WIDE     // trial: the wide variant as a plain persistent loop (grid = 32 workgroups per XCD), see DESIGN.md
-    const int rr_step = NT == 4 ? (int)(gridDim.x >> 3) : 0x40000000;
-    for (int rr = blockIdx.x >> 3;; rr += rr_step) {
-#else
-    const int rr = blockIdx.x >> 3;
-    {
-#endif
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     // ablation 2048 (C = 256): two weight slices per XCD, the two blocks that share a tile group back to back on it
     const int cog = (XQ_ABL & 2048) ? 2 * (xcd & 1) + (rr & 1) : xcd % NG;
     // flags bit 1: walk the batch back to front.  A launch that reads what the previous launch wrote (the next layer of
@@ -444,11 +437,6 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         }
         if (rd + 1 < ROUNDS && !E2) __syncthreads();  // the next round overwrites the planes
     }
-#ifdef XQ_PERSIST_WIDE
-    if (((XQ_ABL & 2048) ? ((rr + rr_step) >> 1) * 4 + (xcd >> 1) : (rr + rr_step) * per + xcd / NG) >= n_groups) break;
-    __syncthreads();                                  // the next group's zero fill overwrites the planes
-#endif
-    }
 }
 
 }  // namespace
@@ -477,12 +465,6 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     const int lds_bytes = (XQ_ABL & 65536) ? 100 * 1024 : LDS_BYTES;      // ablation: one workgroup per CU
     const int per = 8 / (channels / nco);
     const int rows = (n_groups + per - 1) / per;
-#ifdef XQ_PERSIST_WIDE
-    if (wide)
-        hipLaunchKernelGGL(k_wino_conv<4>, dim3((rows < 32 ? rows : 32) * 8), dim3(256), LDS_BYTES_WIDE, (hipStream_t)stream, dev_x, dev_u,
-                           dev_bias, dev_residual, dev_y, batch, channels, flags, n_groups);
-    else
-#endif
     if (wide)
         hipLaunchKernelGGL(k_wino_conv<4>, dim3(rows * 8), dim3(256), LDS_BYTES_WIDE, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
