@@ -37,12 +37,25 @@ def _children_sum(t, first, cnt, ncols):
     return torch.gather(cs, 1, hi) - torch.gather(cs, 1, lo)
 
 
-def test_search_trees_at_full_size():
+def _evaluator(kind):
+    """'pseudo-dense': the device-side pseudo-network through the dense [G,8100] hand-off (xq_engine_expand);
+    'hip-sparse': the hand-written ResNet evaluator (64x3, peaked policy) through the product hand-off -- legal-move logits
+    [G,128] from xq_policy_head_legal into xq_engine_expand_legal."""
+    if kind == "pseudo-dense":
+        return PseudoNet("cuda")
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    net = model.XiangqiNet(64, 3)
+    net.load_state_dict(weights.make_state_dict(64, 3, policy_gain=4.0))
+    return evaluator.make_evaluator(net, "cuda", "hip")[0]
+
+
+@pytest.mark.parametrize("kind", ["pseudo-dense", "hip-sparse"])
+def test_search_trees_at_full_size(kind):
     import torch
     from xiangqi_alphazero_amd import engine, hip
     d = G.corpus()
     picks = [i for i in range(len(d["board"])) if not d["done"][i]]
-    eng = engine.SelfPlayEngine(engine.make_config(GAMES, SIMS, add_noise=False, manual_moves=True), evaluator=PseudoNet("cuda"))
+    eng = engine.SelfPlayEngine(engine.make_config(GAMES, SIMS, add_noise=False, manual_moves=True), evaluator=_evaluator(kind))
     boards = np.stack([d["board"][picks[s % len(picks)]] for s in range(GAMES)])
     sides = np.array([d["side"][picks[s % len(picks)]] for s in range(GAMES)], dtype=np.int8)
     for s in range(GAMES):
