@@ -32,7 +32,8 @@ def _children_sum(t, first, cnt, ncols):
     import torch
     cs = torch.zeros((t.shape[0], ncols + 1), dtype=torch.float64 if t.dtype.is_floating_point else torch.int64, device=t.device)
     torch.cumsum(t[:, :ncols], dim=1, out=cs[:, 1:])
-    lo = first.clamp(min=0).long()
+    # entries beyond a slot's allocation are whatever the (recycled) workspace held: clamp both ends, the callers mask them
+    lo = first.clamp(min=0, max=ncols).long()
     hi = (lo + cnt.long()).clamp(max=ncols)
     return torch.gather(cs, 1, hi) - torch.gather(cs, 1, lo)
 
