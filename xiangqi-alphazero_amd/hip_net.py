@@ -43,6 +43,7 @@ class HipResNetEvaluator:
         # XQ_CONV_REVERSE on every other conv launch (Infinity Cache reuse between layers); XQ_CONV_ALTERNATE=0 for A/B runs
         self.alternate_order = os.environ.get("XQ_CONV_ALTERNATE", "1") != "0"
         # conv kernel variant: 128 output channels per workgroup (XQ_CONV_WIDE) where the width allows, else 64
+        self.micro_batch = int(os.environ.get("XQ_CONV_MICRO_BATCH", "0"))
         want = os.environ.get("XQ_CONV_BLOCK", "")                 # "64" / "128": force one variant (A/B runs)
         if want in ("64", "128") and self.C % int(want) == 0:
             self.co_blocks = [int(want)]
@@ -124,8 +125,22 @@ class HipResNetEvaluator:
     @torch.no_grad()
     def _tower(self, x: torch.Tensor):
         b = x.shape[0]
+        x = x.contiguous()
+        mb = self.micro_batch
+        if mb and b > mb:
+            # trial (XQ_CONV_MICRO_BATCH): the tower run over micro-batches whose activations (3 buffers x mb x 90 x C x 4 B) stay
+            # inside the 256 MB Infinity Cache from one layer to the next; DESIGN.md section 4.1 has the measurement
+            ps, vs = [], []
+            for lo in range(0, b, mb):
+                p, v = self._tower_once(x[lo:lo + mb])
+                ps.append(p.clone()); vs.append(v.clone())
+            return torch.cat(ps), torch.cat(vs)
+        return self._tower_once(x)
+
+    def _tower_once(self, x: torch.Tensor):
+        b = x.shape[0]
         t0, t1, t2, t3 = self._buffers(b)
-        h = hip.stem_conv(x.contiguous(), self.wt_in, self.b_in, t0)
+        h = hip.stem_conv(x, self.wt_in, self.b_in, t0)
         free = [t1, t2, t3]
         rev = self.alternate_order                                   # launches alternate front-to-back / back-to-front:
         for u1, b1, u2, b2 in self._blocks_for(b):                   # each starts on what the previous one wrote last
