@@ -47,7 +47,8 @@
 // dropped, 8 no staging of the next chunks (global -> LDS), 16 no main-loop barriers, 32 no epilogue, 64 no MFMAs,
 // 128 staging loads from one contiguous run (coalesced), 256 staging loads from an L2-resident region, 512 staging issued
 // at the start of a chunk instead of its middle, 1024 weight loads always from chunk 0 (L1/L2-hot), 2048 two weight slices
-// per XCD, 4096 / 8192 weight loads sc1 (L1 bypass) / nt, 16384 output stores nt, 32768 residual loads nt.
+// per XCD, 4096 / 8192 weight loads sc1 (L1 bypass) / nt, 16384 output stores nt, 32768 residual loads nt, 65536 one
+// workgroup per CU (narrow variant), 131072 staging loads nt.
 // Results are wrong by construction; only the launch time is read.
 #ifndef XQ_ABL
 #define XQ_ABL 0
@@ -224,6 +225,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
                 xreg[k] = buf_ld4(xrs, (unsigned)b_lo * 90u * (unsigned)C * 4u + (unsigned)(tid + 256 * k) * 16u, chunk * 8192);
             else if (XQ_ABL & 256)       // ablation: every workgroup reads the same 256 KB (L2-resident): latency without HBM
                 xreg[k] = buf_ld4(xrs, (unsigned)(tid + 256 * k) * 16u, chunk * 8192);
+            else if (XQ_ABL & 131072)    // ablation: staging loads nt (streaming hint)
+                xreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xgk[k], chunk * 32, 2));
             else
                 xreg[k] = buf_ld4(xrs, xgk[k], chunk * 32);
         }
