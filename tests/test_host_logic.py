@@ -251,3 +251,42 @@ def test_torchscript_export_round_trip_matches_reference_outputs(tmp_path):
     np.testing.assert_allclose(vt.numpy().reshape(-1), g["64x3_value"], rtol=0, atol=1e-5)
     with pytest.raises(RuntimeError):                    # no `onnx` in this image: loud, not silent
         export.export_to_onnx(str(tmp_path / "best_model.pt"), str(tmp_path / "model.onnx"))
+
+
+def test_bench_launches_its_own_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two fresh ranks itself (the reference fans out its own workers,
+    parallel_selfplay.py:337-388).  In this container there is no GPU, so both ranks must refuse to run ("needs a GPU":
+    the product path has no CPU fallback) and the launcher must return their non-zero status; a WORLD_SIZE that contradicts
+    --gpus is refused before anything else."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the ranks would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") == 2 and r.stdout.strip() == ""
+    env["WORLD_SIZE"], env["RANK"] = "4", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "refusing to report a run of a different size" in r.stderr
+
+
+def test_bench_workload_label_follows_the_arguments():
+    import importlib.util
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("xq_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    mk = lambda g, s, c, n, p=False: types.SimpleNamespace(games=g, sims=s, channels=c, blocks=n, peaked=p)
+    assert b.workload_label(mk(8192, 800, 256, 10)).startswith("BASELINE configs[2]")
+    assert b.workload_label(mk(1024, 400, 128, 6)).startswith("BASELINE configs[1]")
+    assert b.workload_label(mk(8192, 800, 256, 20)).startswith("per-GPU share of BASELINE configs[3]")
+    assert b.workload_label(mk(4096, 800, 256, 10)).startswith("custom")
+    assert "PEAKED" in b.workload_label(mk(8192, 800, 256, 10, True))
+    flops, tower = b.net_flops(256, 10)
+    assert abs(flops / 1e6 - 2178.0) < 0.5 and abs(b.net_flops(128, 6)[0] / 1e6 - 369.2) < 0.5     # SURVEY section 8a row a17
