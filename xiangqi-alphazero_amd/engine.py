@@ -150,7 +150,9 @@ class SelfPlayEngine:
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            # thread_local: other threads of the process (the RCCL watchdog of a multi-rank run polls events) must not
+            # invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.evaluate_and_expand(self.select())
         except Exception:
             torch.cuda.synchronize(self.device)
