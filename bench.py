@@ -79,6 +79,10 @@ def parse_args():
     ap.add_argument("--graph", action="store_true",
                     help="time HIP-graph replays of the step (engine.capture_step) instead of eager launches; no per-stage breakdown")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher / rendezvous / reduction rehearsal WITHOUT the GPU path: every rank reports fixed stand-in "
+                         "numbers through the same collectives and the line is labelled a rehearsal with value null (CPU test "
+                         "of an 8-rank launch; never a measurement)")
     ap.add_argument("--prewarm", type=int, default=-1,
                     help="untimed network-free steps that bring the staggered slots to the steady-state mix of search "
                          "depths before warm-up (-1: sims+64, 0: off)")
@@ -165,16 +169,25 @@ def measure(args, dev, rank, world, dist, backend, peaked):
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():                  # any initialised group, a forced one-rank RCCL group included
             dist.barrier()
             torch.cuda.synchronize(dev)
 
     prewarm = args.sims + 64 if args.prewarm < 0 else args.prewarm
     if prewarm:
+        # network-free, but through the SAME hand-off as the timed steps: under the sparse protocol the pseudo-policy's logits
+        # are gathered at the ordered legal moves the engine asks for ([G,128] -> xq_engine_expand_legal), so every k_select /
+        # k_expand launch of a run -- prewarm included -- is a product-path launch (the PMC passes average over all of them)
         pp = PseudoPolicy(args.games, dev, 1.2 if peaked else 0.0)
+        zero_legal = torch.zeros((args.games, 128), dtype=torch.float32, device=dev) if sparse else None
         for _ in range(prewarm):
             lg, vl = pp(eng.select())
-            eng.expand(lg, vl, False)
+            if not sparse:
+                eng.expand(lg, vl, False)
+            elif pp.gain > 0:
+                eng.expand_legal(torch.gather(lg, 1, (eng.req_moves.to(torch.int64) & 0xFFFF).clamp_(max=8099)), vl)   # entries past a row's count are ignored
+            else:
+                eng.expand_legal(zero_legal, vl)
         torch.cuda.synchronize(dev)
         del pp
     for _ in range(args.warmup):
@@ -243,7 +256,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
 def reduce_ranks(m, dev, world, dist, backend):
     """-> (max elapsed over ranks, total sims, per-rank sims/s list)."""
     import torch
-    if world == 1:
+    if not dist.is_initialized():
         return m["elapsed"], float(m["sims"]), [m["sims"] / m["elapsed"]]
     tdev = dev if backend == "nccl" else "cpu"
     mine = torch.tensor([m["elapsed"], float(m["sims"])], dtype=torch.float64, device=tdev)
@@ -287,18 +300,18 @@ def complete_games_leg(args, dev, rank, world, dist, backend):
     net.load_state_dict(weights.make_state_dict(128, 6))
     games = args.complete_games
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
     samples, results, st, _ = selfplay.run_games(net, Cfg, games, dev, n_slots=min(games, 1024), seed=args.seed + 7, rank=rank,
                                                  evaluator_kind=args.evaluator, poll_every=256)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     steps = np.array([int(r["steps"]) for r in results])
     mine = [elapsed, float(len(results)), float(st["sims"]), float(steps.sum())]
-    if world > 1:
+    if dist.is_initialized():
         tdev = dev if backend == "nccl" else "cpu"
         t = torch.tensor(mine, dtype=torch.float64, device=tdev)
         parts = [torch.zeros_like(t) for _ in range(world)]
@@ -316,6 +329,31 @@ def complete_games_leg(args, dev, rank, world, dist, backend):
                       "red_wins": st["red_wins"], "black_wins": st["black_wins"], "draws": st["draws"], "samples": int(len(samples))}}
 
 
+def rehearse(args, rank, world, dist):
+    """--rehearse: the launcher, the rendezvous and the reduction of an N-rank run with NO measurement behind them (gloo, no
+    GPU API): rank r contributes elapsed 1 + r/100 s and 1000 (r + 1) simulations through the same all-gather as a real run.
+    The line says so and carries no value."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    m = {"elapsed": 1.0 + rank / 100.0, "sims": 1000.0 * (rank + 1)}
+    elapsed_max, sims_all, per_rank = reduce_ranks(m, "cpu", world, dist, "gloo")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "MCTS simulations/sec (whole node) + self-play games/hour, 256ch x 10blk ResNet", "value": None,
+            "unit": "simulations/s", "n_gpus": world, "rehearsal": True,
+            "note": "launcher / rendezvous / reduction rehearsal: stand-in per-rank numbers, nothing was measured",
+            "ranks": {"launched_by": "bench.py" if os.environ.get("XQ_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
+                      "backend": "gloo" if world > 1 else None, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                      "elapsed_max_s": elapsed_max, "sims_total": sims_all,
+                      "sims_per_s_min": round(min(per_rank), 1), "sims_per_s_max": round(max(per_rank), 1)}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -331,6 +369,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a run of a different size" % (args.gpus, world))
+    if args.rehearse:
+        return rehearse(args, rank, world, dist)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # one rank per GPU; XQ_BENCH_BACKEND=gloo lets several ranks share a card to rehearse the N>1 path on a 1-GPU box
@@ -341,8 +381,16 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # XQ_BENCH_FORCE_GROUP=1: a process group even for ONE rank, so that a one-GPU box runs every collective of the N > 1
+    # path (barriers, the all-gather of the per-rank figures) over RCCL
+    if world > 1 or os.environ.get("XQ_BENCH_FORCE_GROUP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -407,7 +455,7 @@ def main():
                        "prewarm_steps": m["prewarm"],
                        "parallelism": "games sharded across ranks, no data-path collective"},
             "ranks": {"launched_by": "bench.py" if os.environ.get("XQ_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
-                      "backend": backend if world > 1 else None, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                      "backend": backend if dist.is_initialized() else None, "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
                       "sims_per_s_min": round(min(per_rank), 1), "sims_per_s_max": round(max(per_rank), 1)},
             "roofline": roof,
             "breakdown_ms": {"select": round(m["sel_ms"], 3), "evaluate": round(m["nn_ms"], 3), "expand_backup": round(m["exp_ms"], 3)},
@@ -448,7 +496,7 @@ def main():
                                              "(%.1f ms), 1 thread each, %.1f s" % (cb["cores"], cb["sims_per_worker"], args.channels,
                                                                                  args.blocks, cb["predict_ms"], cb["seconds"])}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

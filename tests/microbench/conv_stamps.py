@@ -1,0 +1,96 @@
+"""Per-workgroup timeline of k_wino_conv<4> from a diagnostic build (-DXQ_STAMP=1; not a test):
+    python tests/microbench/conv_stamps.py tests/microbench/lab/libxq_stamp.so [--b 8192] [--c 256]
+For each case (residual yes/no, XQ_CONV_STAGGER off / on) it launches the kernel a few times, reads the stamps of the last
+launch (100 MHz wall clock: kernel entry, end of main loop, last store issued, stores completed) and prints how long a
+workgroup spends in its main loop and in its epilogue, how tightly the workgroups of a round start together, and the
+launch time by HIP events."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from xiangqi_alphazero_amd import hip  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("lib")
+ap.add_argument("--b", type=int, default=8192)
+ap.add_argument("--c", type=int, default=256)
+ap.add_argument("--ticks", type=int, default=500, help="stagger phase step in 10-ns ticks (16 phases)")
+a = ap.parse_args()
+B, Cn = a.b, a.c
+L = C.CDLL(os.path.abspath(a.lib))
+vp, i32 = C.c_void_p, C.c_int
+L.xq_wino_conv3x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+L.xq_wino_conv3x3.restype = i32
+L.xq_debug_read_stamps.argtypes = [vp, i32]
+L.xq_debug_read_stamps.restype = i32
+
+g = torch.Generator(device="cpu").manual_seed(1)
+x = torch.relu(torch.randn(B, 90, Cn, generator=g)).cuda()
+w = (torch.randn(Cn, Cn, 3, 3, generator=g) * (2.0 / (9 * Cn)) ** 0.5).cuda()
+u = hip.wino_transform_weights(w, 128)
+bias = (torch.randn(Cn, generator=g) * 0.1).cuda()
+res = torch.randn(B, 90, Cn, generator=g).cuda()
+y = torch.empty_like(x)
+stream = hip.stream_ptr(x.device)
+n_groups = (B * 15 + 31) // 32
+n_blocks = ((n_groups + 3) // 4) * 8 if Cn == 256 else n_groups * 1
+
+
+def run(flags, r):
+    rc = L.xq_wino_conv3x3(x.data_ptr(), u.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, Cn,
+                           flags, stream)
+    assert rc == 0, rc
+
+
+for label, r, flags in (("residual, lockstep", res, 5), ("no residual, lockstep", None, 5),
+                        ("residual, staggered", res, 5 | 8 | (a.ticks << 8)), ("no residual, staggered", None, 5 | 8 | (a.ticks << 8))):
+    for _ in range(3):
+        run(flags, r)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n):
+        run(flags, r)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    st = np.zeros((n_blocks, 8), dtype=np.uint64)
+    assert L.xq_debug_read_stamps(st.ctypes.data, n_blocks) == 0
+    st = st[st[:, 0] > 0]
+    t0 = st[:, 0].min()
+    start = (st[:, 0] - t0).astype(np.float64) / 100.0           # microseconds
+    main = (st[:, 1] - st[:, 0]).astype(np.float64) / 100.0
+    epi_issue = (st[:, 2] - st[:, 1]).astype(np.float64) / 100.0
+    epi_done = (st[:, 3] - st[:, 1]).astype(np.float64) / 100.0
+    end = (st[:, 3] - t0).astype(np.float64) / 100.0
+    pct = lambda v: "p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile(v, [10, 50, 90, 100]))
+    print("== %s: %.4f ms per launch, %d workgroups stamped, span %.1f us" % (label, ms, len(st), end.max()))
+    print("   main loop (entry -> last MFMA) us: " + pct(main))
+    prol = (st[:, 7] & np.uint64(0xFFFFF)).astype(np.float64) / 100.0
+    st[:, 7] >>= np.uint64(20)
+    st[:, 6] &= np.uint64((1 << 44) - 1)
+    print("   prologue (entry -> first chunk) us: " + pct(prol))
+    clk = (st[:, 7] - st[:, 6]).astype(np.float64) / np.maximum((st[:, 1] - st[:, 0]).astype(np.float64), 1.0) * 100.0
+    print("   in-kernel clock over the main loop (s_memtime / s_memrealtime) MHz: " + pct(clk)
+          + "   => MFMA-only time of a workgroup's 2560 MFMAs per wave at the median clock: %.2f us" % (2560 * 64 / np.percentile(clk, 50)))
+    print("   epilogue, last store issued   us: " + pct(epi_issue))
+    print("   epilogue, stores completed    us: " + pct(epi_done))
+    print("   epilogue phases (wave 0): column half + exchange writes %s | barrier wait %s | reads + row half + stores issued %s" % (
+        "p50 %.2f" % np.percentile((st[:, 4] - st[:, 1]).astype(np.float64) / 100.0, 50),
+        "p50 %.2f" % np.percentile((st[:, 5] - st[:, 4]).astype(np.float64) / 100.0, 50),
+        "p50 %.2f" % np.percentile((st[:, 2] - st[:, 5]).astype(np.float64) / 100.0, 50)))
+    # how many workgroups are inside their epilogue at the same time (sampled every 0.5 us)
+    ts = np.arange(0.0, end.max(), 0.5)
+    e_begin = start + main
+    inside = np.array([np.count_nonzero((e_begin <= t) & (end > t)) for t in ts])
+    print("   workgroups in epilogue at once: mean %.1f  p90 %d  max %d (of 256 CUs)" % (inside.mean(), np.percentile(inside, 90), inside.max()))
+    order = np.argsort(start)
+    gaps = np.diff(start[order])
+    print("   start-time clustering: %d gaps > 5 us between consecutive workgroup starts (rounds in lockstep show ~%d)" %
+          (np.count_nonzero(gaps > 5.0), len(st) // 256 - 1))

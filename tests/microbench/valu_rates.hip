@@ -1,0 +1,134 @@
+// Microbenchmark (gfx950): issue cost of the instruction kinds the conv epilogue is made of, ONE wave per SIMD (256-thread
+// workgroup, one per CU, as k_wino_conv<4> runs).  Cycles per instruction from s_memtime around 512 back-to-back independent
+// instructions of one kind.   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates && ./valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void k(unsigned long long *out, float *sink, float *gbuf) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[8];
+    f32x2 p[8];
+    f32x4 q[8];
+    for (int i = 0; i < 8; ++i) { v[i] = tid * 0.5f + i; p[i] = f32x2{v[i], v[i] + 1.0f}; q[i] = f32x4{v[i], 1.0f, 2.0f, 3.0f}; }
+    float a0 = tid, a1 = tid + 1.f;
+    f32x2 c2 = {1.0001f, 0.9999f};
+    const unsigned lp = wave * 36864 + lane * 16;      // dynamic LDS starts at offset 0 (the kernel has no static LDS)
+    for (int o = tid * 16; o < 147456; o += 4096) *(f32x4 *)(lds + o) = q[0];
+    __syncthreads();
+    unsigned long long t0 = 0, t1 = 0;
+    // accumulators in AGPRs for the accvgpr kinds
+    float acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;
+    asm volatile("v_accvgpr_write_b32 %0, %8\n v_accvgpr_write_b32 %1, %8\n v_accvgpr_write_b32 %2, %8\n v_accvgpr_write_b32 %3, %8\n"
+                 "v_accvgpr_write_b32 %4, %8\n v_accvgpr_write_b32 %5, %8\n v_accvgpr_write_b32 %6, %8\n v_accvgpr_write_b32 %7, %8\n"
+                 : "=a"(acc0), "=a"(acc1), "=a"(acc2), "=a"(acc3), "=a"(acc4), "=a"(acc5), "=a"(acc6), "=a"(acc7) : "v"(a0));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gbuf, 0, 256 * 1024 * 1024, 0x00020000);
+    const unsigned goff = (blockIdx.x * 256 + tid) * 16;
+    for (int rep = 0; rep < 3; ++rep) {
+        __builtin_amdgcn_s_barrier();
+        t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (KIND == 0) {
+#define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a1));
+                    REP8(X)
+#undef X
+                } else if (KIND == 1) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
+                    REP8(X)
+#undef X
+                } else if (KIND == 2) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[i]) : "v"(c2));
+                    REP8(X)
+#undef X
+                } else if (KIND == 3) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(a1));
+                    REP8(X)
+#undef X
+                } else if (KIND == 4) {
+                    asm volatile("v_accvgpr_read_b32 %0, %8\n v_accvgpr_read_b32 %1, %9\n v_accvgpr_read_b32 %2, %10\n v_accvgpr_read_b32 %3, %11\n"
+                                 "v_accvgpr_read_b32 %4, %12\n v_accvgpr_read_b32 %5, %13\n v_accvgpr_read_b32 %6, %14\n v_accvgpr_read_b32 %7, %15\n"
+                                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7])
+                                 : "a"(acc0), "a"(acc1), "a"(acc2), "a"(acc3), "a"(acc4), "a"(acc5), "a"(acc6), "a"(acc7));
+                } else if (KIND == 5) {
+#define X(i) asm volatile("v_max_f32 %0, 0, %0" : "+v"(v[i]));
+                    REP8(X)
+#undef X
+                } else if (KIND == 6) {       // 8 ds_write_b128, lane-linear
+#define X(i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lp), "v"(q[i]), "n"(i * 1024) : "memory");
+                    REP8(X)
+#undef X
+                } else if (KIND == 7) {       // 8 ds_read_b128, lane-linear
+#define X(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[i]) : "v"(lp), "n"(i * 1024) : "memory");
+                    REP8(X)
+#undef X
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else if (KIND == 8) {       // pk_add on values just read from AGPRs (dependent pairs as in the epilogue)
+                    asm volatile("v_accvgpr_read_b32 %0, %2\n v_accvgpr_read_b32 %1, %3" : "=v"(v[0]), "=v"(v[1]) : "a"(acc0), "a"(acc1));
+                    asm volatile("v_accvgpr_read_b32 %0, %2\n v_accvgpr_read_b32 %1, %3" : "=v"(v[2]), "=v"(v[3]) : "a"(acc2), "a"(acc3));
+                    p[0] = f32x2{v[0], v[1]}; p[1] = f32x2{v[2], v[3]};
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[2]) : "v"(p[0]), "v"(p[1]));
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[3]) : "v"(p[2]), "v"(p[1]));
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[4]) : "v"(p[3]), "v"(p[0]));
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[5]) : "v"(p[4]), "v"(p[2]));
+                } else if (KIND == 9) {       // 8 buffer_store_dwordx4 (16 B per lane, lane-linear 1 KB per instruction)
+#define X(i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:%3" ::"v"(q[i]), "v"(goff), "s"(rs), "n"(i * 16 * 0) : "memory");
+                    REP8(X)
+#undef X
+                } else if (KIND == 10) {      // 8 v_mov_b32
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(a1));
+                    REP8(X)
+#undef X
+                }
+            }
+        }
+        if (KIND == 6 || KIND == 9) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i] + p[i].x + p[i].y + q[i].x + q[i].w;
+    if (s == 1234.5f) sink[tid] = s;
+    if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+template <int KIND>
+static void run(const char *name, int per_iter) {
+    unsigned long long *d;
+    float *sink, *gbuf;
+    hipMalloc(&d, 256 * 4 * 8);
+    hipMalloc(&sink, 4096);
+    hipMalloc(&gbuf, 256u * 1024 * 1024);
+    hipFuncSetAttribute((const void *)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256), 150 * 1024, 0, d, sink, gbuf);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(1024);
+    hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double n = 8.0 * 8.0 * per_iter;
+    printf("%-58s median %7.2f  min %7.2f  cycles per instruction (s_memtime ticks / %d)\n", name, h[512] / n, h[0] / n, (int)n);
+    hipFree(d); hipFree(sink); hipFree(gbuf);
+}
+
+int main() {
+    run<0>("v_add_f32 (8 independent chains)", 8);
+    run<3>("v_fma_f32", 8);
+    run<1>("v_pk_add_f32", 8);
+    run<2>("v_pk_fma_f32", 8);
+    run<5>("v_max_f32", 8);
+    run<10>("v_mov_b32", 8);
+    run<4>("v_accvgpr_read_b32", 8);
+    run<8>("2x2 accvgpr_read + 4 dependent v_pk_add (per instruction of 8)", 8);
+    run<6>("ds_write_b128 lane-linear (incl. final drain)", 8);
+    run<7>("ds_read_b128 lane-linear, lgkmcnt(0) per 8", 8);
+    run<9>("buffer_store_dwordx4 1 KB/instr (incl. final drain)", 8);
+    return 0;
+}

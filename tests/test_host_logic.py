@@ -190,6 +190,91 @@ def test_two_rank_gloo_alphazero_loop(tmp_path):
     assert out[0][1] == out[1][1]
 
 
+def test_alphazero_loop_resume_equals_uninterrupted(tmp_path):
+    """`AlphaZeroLoop.resume` = the reference's --resume (training/train.py:569-579, 759-761): a loop stopped after
+    iteration 2 and resumed in a NEW object from checkpoint_iter2.pt continues at iteration 3 and ends in exactly the state
+    of an uninterrupted run -- weights (current and best), optimizer moments and step counts, scheduler epoch and learning
+    rate, total_games, replay buffer and the training_stats history.  World size 1, CPU; the GPU stages are deterministic
+    stand-ins (the real ones run in tests/test_training.py), the optimisation step is real Adam on a real loss."""
+    import types
+    import torch
+    from xiangqi_alphazero_amd import train_loop, training
+    from xiangqi_alphazero_amd.sample_format import RESULT_DTYPE, SAMPLE_DTYPE
+
+    def cfg_for(name):
+        return types.SimpleNamespace(
+            num_channels=16, num_res_blocks=1, num_simulations=8, c_puct=1.5, temperature_threshold=10, num_games_per_iter=4,
+            max_game_length=30, random_opening_moves=2, enable_resign=False, resign_threshold=-0.9, resign_check_steps=5,
+            learning_rate=0.01, weight_decay=1e-4, lr_milestones=[2], lr_gamma=0.1, max_buffer_size=40, min_buffer_size=4,
+            num_epochs=1, batch_size=8, eval_games=4, eval_simulations=4, eval_win_rate=0.55, save_interval=2,
+            num_iterations=4, checkpoint_dir=str(tmp_path / name))
+
+    class Loop(train_loop.AlphaZeroLoop):
+        def _play_shard(self, n_games):                 # 3 samples per game, content a function of (iteration, index)
+            smp = np.zeros(3 * n_games, dtype=SAMPLE_DTYPE)
+            smp["game_seq"] = self.iteration; smp["ply"] = np.arange(3 * n_games); smp["z"] = 1
+            res = np.zeros(n_games, dtype=RESULT_DTYPE)
+            res["winner"] = 1; res["steps"] = 10 + self.iteration
+            return (torch.from_numpy(smp.view(np.uint8).reshape(-1, 640).copy()),
+                    torch.from_numpy(res.view(np.uint8).reshape(-1, 16).copy()))
+
+        def _arena(self):                               # the candidate is promoted in iteration 2, rejected in iteration 4
+            ok = self.iteration == 2
+            return {"new_wins": 3 if ok else 1, "old_wins": 1 if ok else 3, "draws": 0, "win_rate": 0.75 if ok else 0.25,
+                    "model_updated": ok, "games": None}
+
+    def real_adam_step(model, optimizer, scheduler, buffer, config, generator=None, **kw):
+        """a real optimisation step on a loss that depends on the buffer's content and on the generator's order"""
+        order = torch.randperm(len(buffer), generator=generator)
+        x = torch.zeros((4, 15, 10, 9))
+        x.view(4, -1)[:, :4] = order[:16].float().view(4, 4) / 100.0 + float(int(buffer.store[:buffer.count].to(torch.int64).sum()) % 1000) / 1000.0
+        model.train()
+        logits, value = model(x)
+        loss = logits.square().mean() + value.square().mean()
+        optimizer.zero_grad(); loss.backward(); optimizer.step(); scheduler.step()
+        return {"policy_loss": float(loss.detach()), "value_loss": 0.0, "total_loss": float(loss.detach()), "learning_rate": optimizer.param_groups[0]["lr"]}
+
+    saved = training.train_network
+    training.train_network = real_adam_step
+    try:
+        torch.set_num_threads(1)
+        a = Loop(cfg_for("a"), device="cpu", seed=5)
+        a.train()                                       # iterations 1..4, uninterrupted
+        b1 = Loop(cfg_for("b"), device="cpu", seed=5)
+        b1.train(2)                                     # iterations 1..2, then the process "dies"
+        b2 = Loop(cfg_for("b"), device="cpu", seed=5)   # a fresh object (same run seed: it keys the batch order and the games)
+        with torch.no_grad():                           # ... whose weights are NOT what the checkpoint holds
+            for p_ in list(b2.current_model.parameters()) + list(b2.best_model.parameters()):
+                p_.add_(1.0)
+        info = b2.resume(os.path.join(cfg_for("b").checkpoint_dir, "checkpoint_iter2.pt"))
+        assert info["iteration"] == 2 and info["replay_buffer_restored"] and b2.iteration == 2 and b2.total_games == 8
+        assert [e["iteration"] for e in b2.training_stats] == [1, 2]
+        b2.train()                                      # continues with iteration 3
+    finally:
+        training.train_network = saved
+    assert b2.iteration == a.iteration == 4 and b2.total_games == a.total_games == 16
+    for ma, mb in ((a.current_model, b2.current_model), (a.best_model, b2.best_model)):
+        for (ka, ta), (kb, tb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert ka == kb and torch.equal(ta, tb), ka
+    sa, sb = a.optimizer.state_dict(), b2.optimizer.state_dict()
+    assert sa["param_groups"] == sb["param_groups"]
+    for k in sa["state"]:
+        for name in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(torch.as_tensor(sa["state"][k][name]), torch.as_tensor(sb["state"][k][name]))
+    assert a.scheduler.state_dict() == b2.scheduler.state_dict() and a.scheduler.last_epoch == 4
+    assert a.optimizer.param_groups[0]["lr"] == pytest.approx(0.001)        # MultiStepLR [2] x 0.1, stepped once per iteration
+    assert len(a.buffer) == len(b2.buffer) == 40
+    oldest = lambda bf: torch.roll(bf.store, -((bf.head - bf.count) % bf.cap), 0)[:bf.count]
+    assert torch.equal(oldest(a.buffer), oldest(b2.buffer))
+    strip = lambda st: [{k: (v if k != "time" else 0) for k, v in e.items() if k != "self_play"} for e in st]
+    assert strip(a.training_stats) == strip(b2.training_stats) and len(b2.training_stats) == 4
+    # a checkpoint WITHOUT the extra replay file (e.g. one written by the reference) resumes like the reference: empty buffer
+    os.remove(os.path.join(cfg_for("b").checkpoint_dir, "replay_buffer.pt"))
+    b3 = Loop(cfg_for("b"), device="cpu", seed=1)
+    info = b3.resume(os.path.join(cfg_for("b").checkpoint_dir, "checkpoint_iter4.pt"))
+    assert info["iteration"] == 4 and not info["replay_buffer_restored"] and len(b3.buffer) == 0
+
+
 def test_parallel_self_play_signature_matches_reference():
     import inspect
     from xiangqi_alphazero_amd import selfplay

@@ -91,7 +91,8 @@ def evaluate_models(new_model, old_model, config, device="cuda", evaluator_kind:
                          device, first_game=first)
         winners[first:first + mine] = res["winner"].astype(np.int64)
         steps[first:first + mine] = res["steps"].astype(np.int64)
-    if world > 1:                     # disjoint shards: a sum gathers them; every rank ends with the same table
+    if dist.is_initialized():         # disjoint shards: a sum gathers them; every rank ends with the same table (a group of
+                                      # one rank runs the same collective)
         t = torch.from_numpy(np.stack([winners, steps])).to(device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(t, group=group)
         winners, steps = t[0].cpu().numpy(), t[1].cpu().numpy()

@@ -54,6 +54,19 @@
 #define XQ_ABL 0
 #endif
 
+#ifndef XQ_STAMP
+#define XQ_STAMP 0
+#endif
+#ifndef XQ_EPI_OLD
+#define XQ_EPI_OLD 1          // 1: the wide variant with the exchange-plane epilogue (two 64-channel rounds); 0: the one-barrier distributed-reducer epilogue (A/B in DESIGN.md section 4.1)
+#endif
+#if XQ_STAMP
+// Diagnostic builds only (tests/microbench/conv_stamps.py): per-workgroup wall-clock stamps (100 MHz s_memrealtime) at
+// kernel entry, after the main loop, after the epilogue's last store was issued and after those stores completed, plus
+// the hardware id (XCC / SE / CU).  Written to a buffer no other code reads; never in the shipped library.
+__device__ unsigned long long g_xq_stamps[16384 * 8];
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -80,11 +93,14 @@ constexpr int ESTR = 36;                             // floats per tile row of a
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
-constexpr int LDS_BYTES_WIDE = 4 * 3 * TILES * (64 + 4) * 4;                        // exchange planes of a 64-channel round
+constexpr int LDS_BYTES_WIDE = 4 * 3 * 12 * 1024;           // wide epilogue: [reducer wave][source slot][12 slices] of 1 KB (144 KB)
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 // cache-policy variants (aux: bit 0 sc0, bit 1 nt, bit 4 sc1): weight fragments are read once per workgroup and never from
 // this CU's L1 again -- XQ_W_AUX selects how they pass through the caches
@@ -117,6 +133,11 @@ __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
 __device__ __forceinline__ float relu1(float x) {                // one v_max_f32 (fmaxf adds a canonicalising max)
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float max1(float lo, float x) {      // one v_max_f32 against a wave-uniform bound
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(lo), "v"(x));
     return r;
 }
 __device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
@@ -163,6 +184,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     constexpr int NF = 5 * NT, POOL = NF / 2;         // weight fragments per chunk; fragment registers (half a chunk ahead)
 
     const int tid = threadIdx.x, lane = tid & 63, wp = tid >> 6;
+    const int wps = __builtin_amdgcn_readfirstlane(wp);          // the same number in an SGPR
     const int NG = C / NCO;
     const int per = 8 / NG;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
@@ -173,6 +195,17 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     const int tg_fwd = (XQ_ABL & 2048) ? (rr >> 1) * 4 + (xcd >> 1) : rr * per + xcd / NG;
     const int tg = (flags & 2) ? n_groups - 1 - tg_fwd : tg_fwd;
     if (tg_fwd >= n_groups) return;
+#if XQ_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), sm0 = __builtin_amdgcn_s_memtime();
+#endif
+    // flags bit 3 (XQ_CONV_STAGGER): the first workgroup of every CU (the first 256 blocks of the grid are dealt one per CU)
+    // waits for one of 16 phases of `stagger_ticks` x 10 ns.  Equal workgroups otherwise run in lockstep on all 256 CUs, and
+    // so do their epilogues: every round ends in one chip-wide burst of residual reads and output writes at the HBM's
+    // bandwidth while the HBM idles during the main loops.  A CU keeps the phase it starts with for the rest of the launch.
+    if ((flags & 8) && blockIdx.x < 256) {
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) * 5) & 15) * (unsigned)(flags >> 8);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+    }
     const int relu = flags & 1;
     const int T = B * 15;
     const int t0 = tg * TILES;
@@ -241,9 +274,14 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     f32x4 a[5], ub[POOL];
     auto loop_barrier = [&]() __attribute__((always_inline)) { if (!(XQ_ABL & 16)) __syncthreads(); };
     // weight fragment f of a chunk: (q, nt) = (QO[f >> 1], f & 1), processing order of the column frequencies 1,2,3,0,4
+    // Wide variant: wave w's LOCAL N-tile k is the workgroup's N-tile (k + w + 1) & 3, so that the N-tile a wave reduces in
+    // the epilogue (its own number w) is always local tile 3 -- the one whose accumulators are pinned to VGPRs.
+    unsigned ntoff[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) ntoff[k] = (NT == 4 && !XQ_EPI_OLD ? ((k + wps + 1) & 3) : k) * (32 * 16);
     auto load_frag = [&](int chunk, int f, int slot) __attribute__((always_inline)) {
         const int q = (f / NT) == 0 ? 1 : (f / NT) == 1 ? 2 : (f / NT) == 2 ? 3 : (f / NT) == 3 ? 0 : 4;
-        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f % NT) * (32 * 16));
+        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + ntoff[f % NT]);
     };
     auto transform0 = [&]() __attribute__((always_inline)) {
         f32x4 w[5];
@@ -277,13 +315,27 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
                 if (XQ_ABL & 64) {
                     if (FIRST && jj == 0) for (int e = 0; e < 16; ++e) acc[q][nt][e] = 0.0f;
                     asm volatile("" ::"v"(a[q][jj]), "v"(ub[slot][jj]));
+                } else if (NT == 4 && !XQ_EPI_OLD) {
+                    // Wide variant: the WEIGHTS are the MFMA's A operand (rows = output channels) and the transformed input its
+                    // B operand (columns = tiles): a lane then holds FOUR CONSECUTIVE CHANNELS of one tile in every register
+                    // quad of an accumulator, which is what lets the epilogue exchange and store 16 bytes per lane.  Same
+                    // products, same k order: the results are bit-identical to the narrow variant's.
+                    if (FIRST && jj == 0) {
+                        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[slot][jj], a[q][jj], zero, 0, 0, 0);
+                    } else if (nt == 3) {
+                        // 20 accumulator tiles do not fit the 256 AGPRs; the compiler would spill four of them around the
+                        // loop.  The five tiles of local N-tile 3 are pinned to VGPRs ("+v"), the other 15 stay in AGPRs.
+                        // (A dependent MFMA on its own vDst/SrcC needs no software wait states; the first VALU read of these
+                        // registers is fenced in the epilogue.)
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(ub[slot][jj]), "v"(a[q][jj]));
+                    } else {
+                        acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[slot][jj], a[q][jj], acc[q][nt], 0, 0, 0);
+                    }
                 } else if (FIRST && jj == 0) {
                     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], zero, 0, 0, 0);
                 } else if (NT == 4 && nt == 3) {
-                    // wide variant: 20 accumulator tiles do not fit the 256 AGPRs; the compiler would spill four of them
-                    // around the loop.  The five tiles of the last N-tile are pinned to VGPRs ("+v"), the other 15 stay in
-                    // AGPRs.  (A dependent MFMA on its own vDst/SrcC needs no software wait states.)
                     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[q][jj]), "v"(ub[slot][jj]));
                 } else {
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], acc[q][nt], 0, 0, 0);
@@ -333,6 +385,9 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     __syncthreads();
     transform0();
     __syncthreads();                                  // chunk 0 stores into the buffer transform0 just read
+#if XQ_STAMP
+    const unsigned long long stp = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- main loop: chunk c multiplies (a, fragments) of chunk c, transforms chunk c+1 out of buffer (c+1)&1,
     // stores chunk c+2 into buffer c&1 and fetches chunk c+3; one barrier per chunk
@@ -346,10 +401,128 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         chunk_body(c + 2 < NCH ? c + 2 : c + 1, c + 1, std::integral_constant<int, 0>{}, c + 3, std::false_type{});
         loop_barrier();
     }
+#if XQ_STAMP
+    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime(), sm1 = __builtin_amdgcn_s_memtime();
+#endif
     if (XQ_ABL & 32) {                                 // ablation: no epilogue (keep the accumulators observable)
         float sacc = 0.0f;
         for (int q = 0; q < 5; ++q) for (int n = 0; n < NT; ++n) for (int e = 0; e < 16; ++e) sacc += acc[q][n][e];
         if (sacc == 1234.5f) Y[tid] = sacc;
+        return;
+    }
+
+    if constexpr (NT == 4 && !XQ_EPI_OLD) {
+        // ---- wide epilogue: Y = A_r^T M A_c, bias, residual, ReLU with ONE barrier ------------------------------------------
+        // Lane (tile l31, half h) holds, in register quad i of accumulator (q, k), channels 8 i + 4 h .. + 3 of local N-tile k
+        // for ITS tile.  Each wave finishes the column half of the inverse transform in registers (5 frequencies -> 3 output
+        // columns), keeps local N-tile 3 (= the workgroup's N-tile `wave number`) and hands the other three to the waves
+        // that reduce them: wave r sums the four Winograd rows of N-tile r.  Exchange image: [reducer r][slot s][slice 3 i + b]
+        // of 1 KB, lane-linear (16 bytes per lane: every ds_write_b128 / ds_read_b128 is conflict-free), slot s of reducer r
+        // = source wave (r + 1 + s) & 3; 4 x 3 x 12 KB = 144 KB over the staging buffers, which nobody reads after the main
+        // loop's last barrier.  Stores and residual loads go through buffer descriptors: lanes of tiles past the end carry
+        // an out-of-range offset and are dropped by the hardware (no divergent branches).
+        // Everything the epilogue needs per lane is recomputed from the lane number (mbcnt, so that nothing of it is kept
+        // alive -- or spilled -- across the main loop).
+        const int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int eh = elane >> 5, el31 = elane & 31;
+        const int Cs = __builtin_amdgcn_readfirstlane(C);            // keeps every scalar offset below in an SGPR (no waterfall loops)
+        const int eg = t0 + el31, egc = eg < T ? eg : T - 1;
+        const int ebd = egc / 15, et2 = egc - ebd * 15, ety = et2 / 3, etx = et2 - ety * 3;
+        const unsigned ooff_in = (unsigned)(((ebd * 90 + 2 * ety * 9 + 3 * etx) * Cs + cog * NCO + 32 * wps + 4 * eh) * 4);
+        const unsigned ooff = eg < T ? ooff_in : 0xFFFFFFF0u;
+        const unsigned nbytes = (unsigned)B * 90u * (unsigned)C * 4u;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, (int)nbytes, 0x00020000);
+        // no residual: a descriptor of zero records -- every load returns 0.0f without touching memory, one code path
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(R != nullptr ? R : X), 0, R != nullptr ? (int)nbytes : 0, 0x00020000);
+        f32x4 rv[2][3][4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4 *)(bias + cog * NCO + 32 * wps + 8 * i + 4 * eh);
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int yb = 0; yb < 3; ++yb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rv[ya][yb][i] = buf_ld4(rrs, ooff, (unsigned)((ya * 9 + yb) * Cs + 8 * i) * 4u);
+        const float rlo = relu ? 0.0f : -__builtin_inff();            // ReLU or identity as one v_max_f32, no branch
+        // the "+v" MFMAs of local N-tile 3 are invisible to the compiler's hazard recogniser: fence the first VALU read of
+        // the last one's destination by its 16 passes (the other four tiles' last MFMAs are >= 256 cycles older)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[4][3]));
+        // column half on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3, y2 = m1+m2+4 m3+m4
+        auto coltr = [&](int k, int i, f32x4 (&y)[3]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int e = 4 * i + 2 * e2;
+                const f32x2 m0 = {acc[0][k][e], acc[0][k][e + 1]}, m1 = {acc[1][k][e], acc[1][k][e + 1]};
+                const f32x2 m2 = {acc[2][k][e], acc[2][k][e + 1]}, m3 = {acc[3][k][e], acc[3][k][e + 1]};
+                const f32x2 m4 = {acc[4][k][e], acc[4][k][e + 1]};
+                const f32x2 s12 = pk_add2(m1, m2);
+                const f32x2 y0 = pk_add2(pk_add2(m0, m3), s12);
+                const f32x2 y1 = pk_fma2(m3, two, pk_sub2(m1, m2));
+                const f32x2 y2 = pk_add2(pk_fma2(m3, four, s12), m4);
+                y[0][2 * e2] = y0[0]; y[0][2 * e2 + 1] = y0[1];
+                y[1][2 * e2] = y1[0]; y[1][2 * e2 + 1] = y1[1];
+                y[2][2 * e2] = y2[0]; y[2][2 * e2 + 1] = y2[1];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            char *dst = lds + ((((wps + k + 1) & 3) * 3 + (2 - k)) * 12) * 1024 + elane * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 y[3];
+                coltr(k, i, y);
+#pragma unroll
+                for (int yb = 0; yb < 3; ++yb) *(f32x4 *)(dst + (3 * i + yb) * 1024) = y[yb];
+            }
+        }
+        f32x4 own[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) coltr(3, i, own[i]);
+#if XQ_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long sb = __builtin_amdgcn_s_memrealtime();
+#endif
+        __syncthreads();
+#if XQ_STAMP
+        const unsigned long long sc = __builtin_amdgcn_s_memrealtime();
+#endif
+        // row half: Y[0] = (M0 + M1) + M2, Y[1] = (M1 - M2) - M3 (the narrow variant's order), M_p from wave p
+        const char *src = lds + (wps * 3 * 12) * 1024 + elane * 16;
+        auto finish = [&](auto r_tag) __attribute__((always_inline)) {
+            constexpr int RR = decltype(r_tag)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int yb = 0; yb < 3; ++yb) {
+                    f32x4 m[4];
+#pragma unroll
+                    for (int sl = 0; sl < 3; ++sl) m[(RR + 1 + sl) & 3] = *(const f32x4 *)(src + (sl * 12 + 3 * i + yb) * 1024);
+                    m[RR] = own[i][yb];
+                    f32x4 y0 = pk_add4(pk_add4(m[0], m[1]), m[2]), y1 = pk_sub4(pk_sub4(m[1], m[2]), m[3]);
+                    y0 = pk_add4(pk_add4(y0, bv[i]), rv[0][yb][i]);
+                    y1 = pk_add4(pk_add4(y1, bv[i]), rv[1][yb][i]);
+                    y0.x = max1(rlo, y0.x); y0.y = max1(rlo, y0.y); y0.z = max1(rlo, y0.z); y0.w = max1(rlo, y0.w);
+                    y1.x = max1(rlo, y1.x); y1.y = max1(rlo, y1.y); y1.z = max1(rlo, y1.z); y1.w = max1(rlo, y1.w);
+                    buf_st4(yrs, ooff, (unsigned)(yb * Cs + 8 * i) * 4u, y0);
+                    buf_st4(yrs, ooff, (unsigned)((9 + yb) * Cs + 8 * i) * 4u, y1);
+                }
+        };
+        if (wps == 0) finish(std::integral_constant<int, 0>{});
+        else if (wps == 1) finish(std::integral_constant<int, 1>{});
+        else if (wps == 2) finish(std::integral_constant<int, 2>{});
+        else finish(std::integral_constant<int, 3>{});
+#if XQ_STAMP
+        {
+            const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) {
+                unsigned long long *o = g_xq_stamps + (size_t)(blockIdx.x & 16383) * 8;
+                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+                o[4] = sb; o[5] = sc; o[6] = sm0; o[7] = (sm1 << 20) | (stp - st0);
+            }
+        }
+#endif
         return;
     }
 
@@ -440,9 +613,26 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         }
         if (rd + 1 < ROUNDS && !E2) __syncthreads();  // the next round overwrites the planes
     }
+#if XQ_STAMP
+    {
+        const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long *o = g_xq_stamps + (size_t)(blockIdx.x & 16383) * 8;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st1; o[5] = st1; o[6] = sm0; o[7] = (sm1 << 20) | (stp - st0);
+        }
+    }
+#endif
 }
 
 }  // namespace
+
+#if XQ_STAMP
+extern "C" int xq_debug_read_stamps(unsigned long long *host, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xq_stamps), (size_t)n_blocks * 8 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" {
 

@@ -83,6 +83,9 @@ class SelfPlayEngine:
         self.req_counts = self.ws[co:co + self.G * 4].view(torch.int32)
         self.steps = 0
         self._graph = None
+        self._graph_generation = 0
+        self.launch_mode = "eager"                     # "graph" once capture_step has recorded a step
+        self.capture_error = None
 
     # ---- the three stages of a step --------------------------------------------------------------------
     def select(self):
@@ -128,6 +131,8 @@ class SelfPlayEngine:
     def step(self):
         """select -> evaluator -> expand, all asynchronous on the current stream (one graph launch once `capture_step`
         has recorded it)."""
+        if self._graph is not None and getattr(self.evaluator, "generation", 0) != self._graph_generation:
+            self.release_graph()                       # the evaluator reallocated a buffer: the recording holds stale pointers
         if self._graph is not None:
             self._graph.replay()
         else:
@@ -154,14 +159,25 @@ class SelfPlayEngine:
             # invalidate the capture
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.evaluate_and_expand(self.select())
-        except Exception:
+        except hip.XqError:
+            raise                                      # argument / shape / launch errors of our own entry points: never hidden
+        except RuntimeError as e:
+            # ONLY "this evaluator cannot be recorded" (it synchronises, allocates outside torch's pool or launches on
+            # another stream while the stream is capturing) keeps the engine eager; anything else is a real error
+            msg = str(e).lower()
+            if not any(k in msg for k in ("captur", "hiperrorstreamcapture", "cudaerrorstreamcapture", "operation not permitted")):
+                raise
             torch.cuda.synchronize(self.device)
+            self.launch_mode, self.capture_error = "eager", str(e).splitlines()[0][:200]
             return False
         self._graph = g
+        self._graph_generation = getattr(self.evaluator, "generation", 0)
+        self.launch_mode = "graph"
         return True
 
     def release_graph(self):
         self._graph = None
+        self.launch_mode = "eager"
 
     # ---- bookkeeping --------------------------------------------------------------------------------------
     def stats(self, check: bool = True) -> dict:

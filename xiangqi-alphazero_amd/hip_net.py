@@ -52,6 +52,9 @@ class HipResNetEvaluator:
         self.reach = torch.from_numpy(reachable_actions()).to(self.device)
         self.timing = False          # bench.py: HIP events around every conv launch of the timed region
         self._events = []
+        # bumped whenever a device buffer a recorded step points at is REALLOCATED (a weight tensor whose shape changed, a
+        # grown activation / logits buffer): `SelfPlayEngine.step` drops its HIP graph then instead of replaying stale pointers
+        self.generation = 0
         self.update(net)
 
     def update(self, net: XiangqiNet):
@@ -87,6 +90,8 @@ class HipResNetEvaluator:
                 old.copy_(value)
             else:
                 setattr(self, name, value)
+                if old is not None:
+                    self.generation += 1
         self.blocks_by_variant = {cb: [(getattr(self, f"u1_{i}_{cb}"), getattr(self, f"b1_{i}"), getattr(self, f"u2_{i}_{cb}"),
                                         getattr(self, f"b2_{i}")) for i in range(self.num_res_blocks)] for cb in self.co_blocks}
         self.blocks = self.blocks_by_variant[self.co_blocks[-1]]
@@ -104,6 +109,7 @@ class HipResNetEvaluator:
         """Four NHWC activation buffers, grown to the largest batch seen (callers with a varying batch -- the arena
         evaluates only the searching side's slots -- get prefix views, no reallocation per step)."""
         if self._bufs is None or self._bufs[0].shape[0] < b:
+            self.generation += self._bufs is not None
             self._bufs = [torch.empty((b, 90, self.C), dtype=torch.float32, device=self.device) for _ in range(4)]
         return [t[:b] for t in self._bufs]
 
@@ -159,6 +165,7 @@ class HipResNetEvaluator:
         b = x.shape[0]
         p, v = self._tower(x)
         if self._legal is None or self._legal.shape[0] < b:
+            self.generation += self._legal is not None
             self._legal = torch.zeros((b, hip.MAXM), dtype=torch.float32, device=self.device)
         legal = self._legal[:b]
         hip.policy_head_legal(p.view(b, 2880), self.fc_p_w, self.fc_p_b, moves, counts, legal)

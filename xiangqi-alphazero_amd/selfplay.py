@@ -49,6 +49,9 @@ def run_games(model, config, num_games: int, device="cuda", n_slots: Optional[in
     samples, results = eng.drain_device() if device_records else eng.drain()
     st = eng.stats()
     st["evaluator"] = ev_name
+    st["launch"] = eng.launch_mode                     # "graph" (one HIP-graph replay per step) or "eager"
+    if eng.capture_error:
+        st["capture_error"] = eng.capture_error
     return samples, results, st, time.time() - t0
 
 
@@ -71,7 +74,7 @@ def parallel_self_play(model, config, num_workers: Optional[int] = None, use_gpu
         "avg_steps": total_steps / max(len(per_game), 1), "new_samples": len(all_data), "total_time": elapsed,
         "num_workers": int(st.get("games_started", num_games) and (n_slots or min(num_games, 8192))), "mode": "hip",
         "simulations": st["sims"], "leaf_evals": st["leaf_evals"], "root_evals": st["root_evals"],
-        "evaluator": st["evaluator"],
+        "evaluator": st["evaluator"], "launch": st["launch"],
     }
     if return_compact:
         stats["compact_samples"], stats["compact_results"] = samples, results

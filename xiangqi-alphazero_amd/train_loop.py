@@ -15,7 +15,13 @@ Per iteration, exactly the reference's order:
                    and rank 0's decision is broadcast on top, so the replicas cannot drift apart;
   4. checkpoint    every `save_interval` iterations and once more after the last one (train.py:613-615, 636-637), the
                    reference's file format; `training_stats.json` like train.py:620-634.
-Works unchanged with world_size 1 (no process group needed).
+`resume(path)` is the reference's `--resume` (train.py:569-579, 759-761): iteration, total_games, both models, optimizer
+and scheduler come back from a `checkpoint_iter*.pt` (written here or by the reference); the loop then continues at the
+next iteration.  Like the reference the checkpoint itself does not hold the replay buffer; this loop additionally writes
+`replay_buffer.pt` (its compact device records) next to it and restores it when present, so that a resumed run continues
+exactly where an uninterrupted one would be.
+Works unchanged with world_size 1, with or without a process group: every collective below runs whenever a group is
+initialised (a one-rank RCCL group exercises the same calls as eight ranks).
 """
 from __future__ import annotations
 
@@ -38,8 +44,9 @@ class AlphaZeroLoop:
     def __init__(self, config, device="cuda", seed: int = 0, evaluator_kind: str = "hip"):
         self.config = config
         self.device = torch.device(device)
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.grouped = dist.is_initialized()           # collectives run under ANY initialised group, one rank included
+        self.world = dist.get_world_size() if self.grouped else 1
+        self.rank = dist.get_rank() if self.grouped else 0
         self.seed = seed
         self.evaluator_kind = evaluator_kind
         torch.manual_seed(seed)                        # identical initial weights on every rank
@@ -69,7 +76,7 @@ class AlphaZeroLoop:
         cfg = self.config
         t0 = time.time()
         samples, results = self._play_shard(xdist.shard_games(cfg.num_games_per_iter, self.world, self.rank))
-        if self.world > 1:
+        if self.grouped:
             samples = xdist.all_gather_records_device(samples)
             results = xdist.all_gather_records_device(results)
         self.buffer.extend(samples)
@@ -88,10 +95,13 @@ class AlphaZeroLoop:
         (`training.train_network(ddp=True)`); `config.ddp = False` falls back to training on rank 0 alone.  Either way one
         flat weight broadcast from rank 0 closes the step, so the replicas cannot drift."""
         stats = {}
-        ddp = self.world > 1 and bool(getattr(self.config, "ddp", True)) and self.device.type == "cuda"
+        ddp = self.grouped and bool(getattr(self.config, "ddp", True)) and self.device.type == "cuda"
+        # the batch order is a function of (seed, iteration): the same on every rank, and the same in a resumed run
+        gen = torch.Generator().manual_seed(self.seed * 1000003 + 7919 * self.iteration + 17)
         if ddp or self.rank == 0:
-            stats = training.train_network(self.current_model, self.optimizer, self.scheduler, self.buffer, self.config, ddp=ddp)
-        if self.world > 1:
+            stats = training.train_network(self.current_model, self.optimizer, self.scheduler, self.buffer, self.config,
+                                           generator=gen, ddp=ddp)
+        if self.grouped:
             xdist.broadcast_weights(self.current_model, src=0, device=self.device)
         return stats
 
@@ -101,7 +111,7 @@ class AlphaZeroLoop:
     def evaluate(self) -> dict:
         stats = self._arena()
         stats.pop("games", None)
-        if self.world > 1:                             # one verdict for all replicas: rank 0's
+        if self.grouped:                               # one verdict for all replicas: rank 0's
             flag = torch.tensor([1 if stats["model_updated"] else 0], dtype=torch.int64,
                                 device=self.device if dist.get_backend() == "nccl" else "cpu")
             dist.broadcast(flag, src=0)
@@ -116,6 +126,38 @@ class AlphaZeroLoop:
         if self.rank == 0:
             training.save_checkpoint(self.config.checkpoint_dir, iteration, self.current_model, self.best_model,
                                      self.optimizer, self.scheduler, self.total_games, is_best=True)
+            b = self.buffer                            # beside the reference's files: the compact replay records, oldest first
+            oldest = (b.head - b.count) % b.cap
+            rec = torch.roll(b.store, -oldest, 0)[:b.count].cpu()
+            torch.save({"iteration": iteration, "records": rec}, os.path.join(self.config.checkpoint_dir, "replay_buffer.pt"))
+
+    def resume(self, path: str) -> dict:
+        """`AlphaZeroTrainer.load_checkpoint` + `--resume` (train.py:569-579, 759-761): restore iteration, total_games, both
+        models, optimizer and scheduler from `path` (a `checkpoint_iter*.pt` of this loop or of the reference; loaded with
+        `weights_only=True`); `train()` then continues with iteration + 1.  If `replay_buffer.pt` of the same iteration lies
+        beside the checkpoint the replay buffer is restored too (the reference restarts with an empty one), and so is the
+        `training_stats.json` history up to that iteration.  Every rank of a multi-rank run calls this with the same file."""
+        info = training.load_checkpoint(path, self.current_model, self.best_model, self.optimizer, self.scheduler,
+                                        map_location=self.device)
+        self.iteration = int(info["iteration"])
+        self.total_games = int(info["total_games"])
+        folder = os.path.dirname(os.path.abspath(path))
+        info["replay_buffer_restored"] = False
+        rb = os.path.join(folder, "replay_buffer.pt")
+        if os.path.exists(rb):
+            saved = torch.load(rb, map_location="cpu", weights_only=True)
+            if int(saved.get("iteration", -1)) == self.iteration:
+                self.buffer = training.ReplayBuffer(self.config.max_buffer_size, self.device)
+                self.buffer.extend(saved["records"])
+                info["replay_buffer_restored"] = True
+        st = os.path.join(folder, "training_stats.json")
+        if os.path.exists(st):
+            try:
+                with open(st) as f:
+                    self.training_stats = [e for e in json.load(f) if int(e.get("iteration", 0)) <= self.iteration]
+            except (ValueError, OSError):
+                self.training_stats = []
+        return info
 
     # ---- train.py:581-638 ------------------------------------------------------------------------------------
     def train(self, num_iterations: Optional[int] = None) -> list:

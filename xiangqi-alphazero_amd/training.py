@@ -78,31 +78,69 @@ class ReplayBuffer:
         return states, pi, z
 
 
+def prepare_ddp(model, device, group=None):
+    """The data-parallel form of `model`, built ONCE and kept for the model's lifetime: BatchNorm -> SyncBatchNorm IN PLACE
+    (same Parameters and buffers, same state_dict keys: checkpoints, `broadcast_weights` and the evaluators are unaffected)
+    and one DistributedDataParallel wrapper (its construction broadcasts the parameters, so it is not repeated per call).
+    SIDE EFFECT on the caller's model: from here on a training-mode forward is a collective -- every rank of `group` must
+    take part in it; `train_network(ddp=False)` refuses such a model under a multi-rank group (`revert_sync_batchnorm`
+    undoes the conversion)."""
+    wrapper = model.__dict__.get("_xq_ddp")
+    if wrapper is None:
+        torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, group)       # in place for the children
+        device = torch.device(device)
+        wrapper = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[device.index] if device.type == "cuda" else None, process_group=group, broadcast_buffers=False)
+        model.__dict__["_xq_ddp"] = wrapper       # not a registered submodule (the wrapper already holds the model)
+    return wrapper
+
+
+def revert_sync_batchnorm(model) -> None:
+    """Undo `prepare_ddp`: every SyncBatchNorm becomes a BatchNorm2d again (same tensors) and the cached wrapper is dropped."""
+    model.__dict__.pop("_xq_ddp", None)
+
+    def walk(mod):
+        for name, child in list(mod.named_children()):
+            if isinstance(child, torch.nn.SyncBatchNorm):
+                bn = torch.nn.BatchNorm2d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
+                bn.weight, bn.bias = child.weight, child.bias
+                bn.running_mean, bn.running_var, bn.num_batches_tracked = child.running_mean, child.running_var, child.num_batches_tracked
+                bn.train(child.training)
+                setattr(mod, name, bn)
+            else:
+                walk(child)
+    walk(model)
+
+
 def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shuffle: bool = True,
                   generator: Optional[torch.Generator] = None, ddp: bool = False, group=None) -> Dict[str, float]:
     """One call of the reference's train_network (train.py:376-447) on the device-resident buffer.
 
-    `ddp=True` under torch.distributed (every rank holds the same buffer and the same weights, as AlphaZeroLoop keeps
-    them): every batch is split across the ranks, BatchNorm statistics are synchronised (SyncBatchNorm: the batch
-    statistics of the WHOLE batch, as on the reference's single device) and the gradients are summed by bucketed
+    `ddp=True` under an initialised torch.distributed group (every rank holds the same buffer and the same weights, as
+    AlphaZeroLoop keeps them): every batch is split across the ranks, BatchNorm statistics are synchronised (SyncBatchNorm:
+    the batch statistics of the WHOLE batch, as on the reference's single device) and the gradients are summed by bucketed
     all-reduce overlapped with backward (DistributedDataParallel) -- the update is the reference's full-batch update, the
-    replicas stay identical, and each GPU runs 1/world of the forward/backward work.  The batch order comes from
-    `generator` (or a generator seeded identically on every rank)."""
+    replicas stay identical, and each GPU runs 1/world of the forward/backward work.  The conversion and the wrapper are
+    made once per model (`prepare_ddp`, which documents the side effect on the caller's model).  The batch order comes
+    from `generator` (or a generator seeded identically on every rank)."""
     if len(buffer) < config.min_buffer_size:
         return {}
     import torch.distributed as dist
-    world = dist.get_world_size(group) if (ddp and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+    use_ddp = bool(ddp and dist.is_initialized())
+    world = dist.get_world_size(group) if use_ddp else 1
+    rank = dist.get_rank(group) if use_ddp else 0
     n = len(buffer)
     model.train()
     net = model
-    if world > 1:
-        torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, group)       # in place for the children; same Parameters
-        net = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[buffer.device.index] if buffer.device.type == "cuda" else None, process_group=group,
-            broadcast_buffers=False)
+    if use_ddp:
+        net = prepare_ddp(model, buffer.device, group)
         if generator is None:                                              # one order for all ranks
             generator = torch.Generator().manual_seed(int(scheduler.last_epoch) * 7919 + 17)
+    elif dist.is_initialized() and dist.get_world_size(group) > 1 and any(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules()):
+        # a training-mode forward of this model is a collective; taken by a subset of the ranks it would hang
+        raise hip.XqError("train_network(ddp=False): the model still carries SyncBatchNorm from a ddp step and the process "
+                          "group has %d ranks; train with ddp=True on every rank or call revert_sync_batchnorm(model) first"
+                          % dist.get_world_size(group))
     total_p = total_v = 0.0
     batches = 0
     for _ in range(config.num_epochs):
@@ -111,12 +149,12 @@ def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shu
             idx = order[lo:lo + config.batch_size]
             full = idx.numel()
             scale = 1.0
-            if world > 1 and full >= world:                            # this rank's slice of the batch
+            if use_ddp and full >= world:                              # this rank's slice of the batch
                 idx = idx.tensor_split(world)[rank]
                 scale = float(world)                                   # DDP averages the ranks' gradients
             states, target_pi, target_z = buffer.batch(idx)
             logits, value = net(states)
-            if world > 1 and full >= world:
+            if use_ddp and full >= world:
                 # sums over the local slice, scaled so that DDP's average over ranks is the full-batch mean loss
                 policy_loss = -torch.sum(target_pi * F.log_softmax(logits, dim=1)) / full
                 value_loss = torch.sum((value - target_z) ** 2) / full
@@ -130,7 +168,7 @@ def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shu
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             optimizer.step()
             pv = torch.stack([policy_loss.detach(), value_loss.detach()])
-            if world > 1 and full >= world:
+            if use_ddp and full >= world:
                 dist.all_reduce(pv, group=group)                       # the slices' shares add up to the batch's losses
             total_p += pv[0].item()
             total_v += pv[1].item()
