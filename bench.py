@@ -325,6 +325,8 @@ def complete_games_leg(args, dev, rank, world, dist, backend):
             "games_finished": int(n_games), "wall_s": round(wall, 2), "games_per_hour": round(n_games * 3600.0 / wall, 1),
             "simulations_per_s": round(sum(p[2] for p in parts) / wall, 1),
             "mean_plies_per_game": round(sum(p[3] for p in parts) / max(n_games, 1), 2),
+            "launch": st.get("launch"), "slot_policy": "games_target = games: finished slots idle until the last game ends (tail-limited; "
+                                                       "the refilling figure is tools/measure_games_per_hour.py --refill)",
             "rank0": {"plies_p10": int(np.percentile(steps, 10)), "plies_p90": int(np.percentile(steps, 90)),
                       "red_wins": st["red_wins"], "black_wins": st["black_wins"], "draws": st["draws"], "samples": int(len(samples))}}
 
@@ -495,6 +497,20 @@ def main():
                                    "sample": "%d workers x one %d-simulation search from the opening, %dx%d fp32 batch-1 predict "
                                              "(%.1f ms), 1 thread each, %.1f s" % (cb["cores"], cb["sims_per_worker"], args.channels,
                                                                                  args.blocks, cb["predict_ms"], cb["seconds"])}
+            if gph is not None:
+                # the metric's second unit for the CPU side (sims/s, games/h, core count): the same
+                # port at the games/hour leg's configuration (128x6, 400 sims/move), a bounded search sample, turned into
+                # games/hour with the game length MEASURED on the complete games of this run (a complete CPU game at 400
+                # sims/move is ~13 minutes per core: outside a bench run)
+                cg = cpu_baseline.run(128, 6, budget_s=min(8.0, args.cpu_seconds))
+                spg = 400.0 * gph["mean_plies_per_game"]
+                out["cpu_baseline"]["games_per_hour"] = {
+                    "value": round(cg["value"] * 3600.0 / spg, 2), "unit": "games/hour", "cores": cg["cores"], "kind": "port",
+                    "simulations_per_s": round(cg["value"], 2),
+                    "sample": "%d workers x one %d-simulation search, 128x6 fp32 batch-1 predict (%.1f ms), %.1f s; games/hour = "
+                              "simulations/s x 3600 / (400 sims/move x %.1f plies per game measured on this run's complete games)"
+                              % (cg["cores"], cg["sims_per_worker"], cg["predict_ms"], cg["seconds"], gph["mean_plies_per_game"]),
+                    "gpu_over_cpu": round(gph["games_per_hour"] / max(cg["value"] * 3600.0 / spg, 1e-9), 1)}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

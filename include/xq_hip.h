@@ -156,7 +156,11 @@ typedef struct xq_engine_stats {
  * n_games * (1 + (num_simulations+1)*XQ_MAXM) nodes * 24 B -- sized for 288 GB HBM, no per-node malloc). */
 size_t xq_engine_workspace_bytes(const xq_engine_config *cfg);
 
-/* Carves `ws` (>= workspace_bytes, 256-byte aligned), zeroes state, every slot starts a new game.
+/* Carves `ws` (>= workspace_bytes, 256-byte aligned) and initialises the engine: boards, history rings, per-slot state
+ * words (allocation marks and RNG counters among them), request counts, root prior / injected-noise tables, ring
+ * counters and the statistics are zeroed, and every slot starts a new game at its first step.  The tree arenas (N, W, P, action, first-child, meta) are NOT cleared: a slot's nodes are valid only below its
+ * allocation mark (bump allocator, reset at every move), nothing in the engine reads past it, and whatever the caller's
+ * buffer held before stays there -- tools that walk the arenas (`SelfPlayEngine.arena_views`) must stop at the mark.
  * dev_inject: uint64[n_games][4][inject_len] or NULL. */
 int xq_engine_init(xq_engine *eng, const xq_engine_config *cfg, void *ws, size_t ws_bytes,
                    const uint64_t *dev_inject, void *stream);

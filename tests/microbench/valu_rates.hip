@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long *out, float *sink
     asm volatile("v_accvgpr_write_b32 %0, %8\n v_accvgpr_write_b32 %1, %8\n v_accvgpr_write_b32 %2, %8\n v_accvgpr_write_b32 %3, %8\n"
                  "v_accvgpr_write_b32 %4, %8\n v_accvgpr_write_b32 %5, %8\n v_accvgpr_write_b32 %6, %8\n v_accvgpr_write_b32 %7, %8\n"
                  : "=a"(acc0), "=a"(acc1), "=a"(acc2), "=a"(acc3), "=a"(acc4), "=a"(acc5), "=a"(acc6), "=a"(acc7) : "v"(a0));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gbuf, 0, 256 * 1024 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gbuf, 0, 512 * 1024 * 1024, 0x00020000);
     const unsigned goff = (blockIdx.x * 256 + tid) * 16;
     for (int rep = 0; rep < 3; ++rep) {
         __builtin_amdgcn_s_barrier();
@@ -84,6 +84,26 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long *out, float *sink
 #define X(i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:%3" ::"v"(q[i]), "v"(goff), "s"(rs), "n"(i * 16 * 0) : "memory");
                     REP8(X)
 #undef X
+                } else if (KIND >= 11 && KIND <= 14) {
+                    // the conv epilogue's two global access shapes, fresh lines every instruction (activations [pos][256 ch] f32):
+                    // 11 / 13: thread (tile = lane >> 3, quad = lane & 7): 8 lanes cover one 128-byte line (round-2 epilogue);
+                    // 12 / 14: lane (tile = lane & 31, half = lane >> 5): 32 tiles x 32 bytes per instruction (MFMA layout).
+                    // 11, 12 stores; 13, 14 loads.  Rows are 1 KB apart (C = 256), tiles 3 rows apart.
+                    const unsigned pp = (unsigned)(it * 8 + u) * 4u;      // + i: instruction number 0..255, every one on fresh lines
+                    const bool lines = KIND == 11 || KIND == 13;
+                    const unsigned trow = lines ? (unsigned)(wave * 8 + (lane >> 3)) : (unsigned)(lane & 31);
+                    const unsigned base = lines
+                        ? (((unsigned)blockIdx.x * 32u + trow) * 64u + pp / 8u) * 1024u + (pp % 8u) * 128u + (unsigned)(lane & 7) * 16u
+                        : (((unsigned)blockIdx.x * 32u + trow) * 64u + pp / 4u) * 1024u + (unsigned)wave * 128u + (unsigned)(lane >> 5) * 16u;
+                    if (KIND <= 12) {
+#define X(i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:%3" ::"v"(q[i]), "v"(base), "s"(rs), "n"((KIND == 11 ? 128 : 32) * i) : "memory");
+                        X(0) X(1) X(2) X(3)
+#undef X
+                    } else {
+#define X(i) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(q[i]) : "v"(base), "s"(rs), "n"((KIND == 13 ? 128 : 32) * i) : "memory");
+                        X(0) X(1) X(2) X(3)
+#undef X
+                    }
                 } else if (KIND == 10) {      // 8 v_mov_b32
 #define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(a1));
                     REP8(X)
@@ -91,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long *out, float *sink
                 }
             }
         }
-        if (KIND == 6 || KIND == 9) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (KIND == 6 || KIND == 9 || KIND >= 11) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         t1 = __builtin_amdgcn_s_memtime();
     }
     float s = 0;
@@ -106,7 +126,7 @@ static void run(const char *name, int per_iter) {
     float *sink, *gbuf;
     hipMalloc(&d, 256 * 4 * 8);
     hipMalloc(&sink, 4096);
-    hipMalloc(&gbuf, 256u * 1024 * 1024);
+    hipMalloc(&gbuf, 512u * 1024 * 1024);
     hipFuncSetAttribute((const void *)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256), 150 * 1024, 0, d, sink, gbuf);
     hipDeviceSynchronize();
@@ -130,5 +150,9 @@ int main() {
     run<6>("ds_write_b128 lane-linear (incl. final drain)", 8);
     run<7>("ds_read_b128 lane-linear, lgkmcnt(0) per 8", 8);
     run<9>("buffer_store_dwordx4 1 KB/instr (incl. final drain)", 8);
+    run<11>("store dwordx4, 8 lanes per 128-B line (incl. drain)", 4);
+    run<12>("store dwordx4, 32 tiles x 32 B per instr (incl. drain)", 4);
+    run<13>("load  dwordx4, 8 lanes per 128-B line (incl. drain)", 4);
+    run<14>("load  dwordx4, 32 tiles x 32 B per instr (incl. drain)", 4);
     return 0;
 }

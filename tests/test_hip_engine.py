@@ -284,6 +284,26 @@ def test_arena_gate_matches_reference(eng_mod):
             assert int(r["n_samples"]) == 0
 
 
+def test_arena_sparse_merge_equals_per_model_dense_evaluation(eng_mod):
+    """The arena's product path (both hand-written evaluators over the whole slot batch, the other model's requests masked
+    to zero, results merged on the device: no host round trip per step) plays the same games as evaluating each model on
+    its own slots through the dense protocol (index_select + xq_engine_expand), for two different real networks."""
+    from xiangqi_alphazero_amd import arena, evaluator, model, weights
+    nets = []
+    for seed in (1, 2):
+        n = model.XiangqiNet(64, 2)
+        n.load_state_dict(weights.make_state_dict(64, 2, seed=seed, policy_gain=4.0))
+        nets.append(n)
+    en, _ = evaluator.make_evaluator(nets[0], "cuda", "hip")
+    eo, _ = evaluator.make_evaluator(nets[1], "cuda", "hip")
+    sparse = arena.play_arena(en, eo, 6, 12, 24)
+    dense = arena.play_arena(lambda x: en(x), lambda x: eo(x), 6, 12, 24)        # plain callables: the dense protocol
+    assert [int(r["slot"]) for r in sparse] == list(range(6))
+    assert [(int(r["winner"]), int(r["steps"])) for r in sparse] == [(int(r["winner"]), int(r["steps"])) for r in dense]
+    odd_first = arena.play_arena(en, eo, 3, 12, 24, first_game=1)                 # a shard that starts on an odd game
+    assert [(int(r["winner"]), int(r["steps"])) for r in odd_first] == [(int(r["winner"]), int(r["steps"])) for r in sparse[1:4]]
+
+
 def test_mcts_shim_has_the_reference_call_shape(eng_mod):
     """`MCTS(model, num_simulations, c_puct).search(game, T, add_noise)` / `.get_action` (mcts.py:76-174) on the engine,
     with a duck-typed game object carrying the reference's attribute names."""

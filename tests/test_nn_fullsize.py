@@ -201,6 +201,66 @@ def test_hip_tower_logits_and_probs_vs_reference_golden(tag, ch, nb, gain):
         assert (np.abs(np.take_along_axis(logits, top, axis=1) - g[tag + "_top_logit"]) / sc).max() < 2e-5
 
 
+def winograd_margin_case(ch, nb, gain, decades, big_channels, big, boards=48):
+    """Errors against the float64 evaluation of the SAME folded weights, for generator weights re-parameterised by
+    `weights.rescale_channels` (activation scales spread over 10^+-decades, `big_channels` stream channels at `big`):
+    -> dict with, for the hand-written evaluator ("hip") and for the plain PyTorch float32 module evaluated on the CPU
+    ("torch": model.py:87-107 as the reference itself runs it), max |p - p64|, max |v - v64| and
+    max |logit - logit64| / max |logit64|; plus the largest activation of the tower."""
+    import torch
+    from xiangqi_alphazero_amd import evaluator, model, weights
+    d = G.corpus()
+    idx = np.linspace(0, len(d["board"]) - 1, boards).astype(int)
+    x = torch.from_numpy(np.stack([O.encode_state(d["board"][i], int(d["side"][i])) for i in idx])).cuda()
+    sd = weights.rescale_channels(weights.make_state_dict(ch, nb, policy_gain=gain), nb, decades, big_channels=big_channels, big=big)
+    net = model.XiangqiNet(ch, nb)
+    net.load_state_dict(sd)
+    inf = model.InferenceNet(net)
+    l64, v64 = _f64_network(inf, x, chunk=16)
+    p64 = torch.softmax(l64, 1)
+    out = {}
+    ev, _ = evaluator.make_evaluator(net, "cuda", "hip")
+    net.eval()
+    with torch.no_grad():                                    # the reference's own arithmetic: the unfolded eval-mode module on the CPU
+        lc, vc = net(x.cpu())
+    for name, (logits, value) in (("hip", ev(x, full_policy=True)), ("torch", (lc.cuda(), vc.cuda()))):
+        p = torch.softmax(logits.double(), 1)
+        out[name] = {"prob": float((p - p64).abs().max()), "value": float((value.double().view(-1) - v64).abs().max()),
+                     "logit_rel": float((logits.double() - l64).abs().max() / l64.abs().max())}
+    out["largest_activation"] = float(ev._bufs[0][:x.shape[0]].abs().max())        # one of the tower's activation buffers
+    out["max_abs_logit"] = float(l64.abs().max())
+    return out
+
+
+@pytest.mark.parametrize("gain,decades,big_channels,big", [(1.0, 0.0, 0, 1e3), (1.0, 2.0, 4, 1e3), (1.0, 6.0, 4, 1e6), (8.0, 0.0, 0, 1e3), (8.0, 2.0, 4, 1e3)])
+def test_winograd_tower_margin_under_scale_spread(gain, decades, big_channels, big):
+    """The 1e-5 contract's DOMAIN OF VALIDITY as a tested statement (training/model.py:87-107).  The
+    golden fixtures only feed He-scaled weights and unit-scale activations; F(2,3) x F(3,3) at the points 0, +-1, 2, inf adds
+    neighbouring pixels with weights up to 4, so the question was how its rounding grows with the operands' dynamic range.
+    Here the 256x20 network is re-parameterised WITHOUT changing its function (`weights.rescale_channels`): per-channel
+    activation scales spread log-uniformly over 10^-D .. 10^+D in every convolution (what folded BatchNorm scales of a
+    trained net can do) and `big_channels` residual-stream channels carrying activations of magnitude `big`; 48 positions,
+    float64 evaluation of the same folded weights as the truth.  Measured (profiles/r03_winograd_margin.json) and asserted:
+      * the tower's error does NOT grow with the spread (D up to 6, activations up to 1e6: the transforms act per channel, and
+        a per-channel scale commutes with them): logits within 4e-6 of the row's largest |logit| (measured 1.9 - 2.3e-6; the
+        reference's own float32 module on the CPU: 5 - 6e-7), value within 1e-5 (measured < 1e-6), in every case;
+      * probabilities are within 1e-5 wherever the logit scale is that of a real policy head (policy_gain 1: max |logit| 7.7,
+        measured 2.5 - 4.1e-7): dp <= p (1 - p) dlogit <= 1/4 x 4e-6 x max |logit| stays below 1e-5 up to max |logit| ~ 10
+        in the worst case and ~ 60 as measured;
+      * the synthetic PEAKED variant (policy_gain 8: max |logit| 62, top probability ~1) is at the edge: 0.8 - 1.4e-5 against
+        float64 on these 48 positions (the CPU float32 module: 1.5 - 2.8e-6), asserted < 3e-5.  Against the REFERENCE's
+        recorded float32 outputs the same network is within 1e-5 on the golden positions
+        (test_hip_tower_logits_and_probs_vs_reference_golden)."""
+    r = winograd_margin_case(256, 20, gain, decades, big_channels, big)
+    assert r["hip"]["value"] < TOL and r["hip"]["logit_rel"] < 4e-6, r
+    if gain <= 1.0:
+        assert r["hip"]["prob"] < TOL, r
+    else:
+        assert r["hip"]["prob"] < 3e-5, r
+    if big_channels:
+        assert r["largest_activation"] > 0.1 * big, r                  # the large activations are really there
+
+
 def _search_priors(logits_rows, boards, sides, is_probs=False, evaluator=None):
     """Root priors the engine derives from the given policy rows -- or, with `evaluator`, from the evaluator in its own
     protocol (engine.evaluate_and_expand: legal-move logits for the hand-written one) -- one search-only slot per position."""
@@ -252,6 +312,56 @@ def test_unreachable_column_edge_of_the_pruned_policy_row():
     want = torch.softmax(torch.from_numpy(row[legal].astype(np.float64)), 0).numpy()
     np.testing.assert_allclose(r_pruned["prior"], want, rtol=0, atol=TOL)
     assert abs(float(np.sum(r_pruned["prior"])) - 1.0) < 1e-5
+
+
+def test_sparse_handoff_extreme_gap_and_non_finite_logits():
+    """The product hand-off (xq_engine_expand_legal: softmax over the LEGAL logits) on rows the network never produces but the
+    contract must still define: a logit gap beyond float32's exp range among the legal moves, and NaN / +inf / all
+    -inf logits.  Expected values restate mcts.py:176-188 on model.py:122's float32 softmax over all 8100 columns (-inf in
+    the non-legal ones, so that both protocols see the same numbers): the gap rows renormalise to the same priors (1e-7),
+    every non-finite row makes prob_sum NaN and takes the reference's uniform fallback 1/n in float64 (mcts.py:184-186)."""
+    import torch
+    from xiangqi_alphazero_amd import engine
+    g = O.Game()
+    legal = np.array(O.legal_actions(g.board.reshape(90), g.current_player), dtype=np.int64)
+    n = len(legal)
+    rng = np.random.default_rng(11)
+    base = rng.normal(0, 1.0, n).astype(np.float32)
+    rows = []
+    for gap in (150.0, 95.0, 60.0):                       # total underflow / denormal range / plain
+        r = base.copy(); r[7] = base.max() + gap
+        rows.append(r)
+    r = base.copy(); r[3] = np.nan; rows.append(r)
+    r = base.copy(); r[5] = np.inf; rows.append(r)
+    rows.append(np.full(n, -np.inf, dtype=np.float32))
+    k = len(rows)
+    ll = np.zeros((k, 128), dtype=np.float32)
+    for i, r in enumerate(rows):
+        ll[i, :n] = r
+    eng = engine.SelfPlayEngine(engine.make_config(k, 4, add_noise=False, manual_moves=True))
+    for s_ in range(k):
+        eng.set_position(s_, g.board, int(g.current_player))
+    eng.select()
+    eng.expand_legal(torch.from_numpy(ll).cuda(), torch.zeros(k, dtype=torch.float32, device="cuda"))
+    got = [eng.read_root(s_) for s_ in range(k)]
+    for i, r in enumerate(rows):
+        assert list(got[i]["actions"]) == list(legal)
+        full = np.full(8100, -np.inf, dtype=np.float32)
+        full[legal] = r
+        sm = torch.softmax(torch.from_numpy(full), 0).numpy()          # model.py:122 (float32, CPU)
+        p = sm[legal]
+        tot = np.float32(0.0)
+        for v in p:                                                     # builtin sum(): sequential float32 (mcts.py:181)
+            tot = np.float32(tot + v)
+        if tot > 0:                                                     # NaN compares False: the fallback, as in the reference
+            want = (p / tot).astype(np.float64)
+            assert not got[i]["prior_is_f64"]
+            np.testing.assert_allclose(got[i]["prior"], want, rtol=0, atol=1e-7)
+            assert abs(float(got[i]["prior"].sum()) - 1.0) < 1e-6
+        else:
+            assert i >= 3                                               # only the non-finite rows end here
+            np.testing.assert_array_equal(got[i]["prior"], np.full(n, 1.0 / n))
+    assert got[0]["prior"][7] == 1.0 and float(np.delete(got[0]["prior"], 7).max()) == 0.0
 
 
 @pytest.mark.parametrize("tag,ch,nb,gain", GOLD2)

@@ -5,8 +5,10 @@ each), colours alternate by game index, every move is `MCTS.get_action(temperatu
 `win_rate = (new_wins + 0.5 draws) / games >= eval_win_rate` promotes the candidate.  Deterministic (no random
 draws at all), so results are checked game by game against the reference's own arena under stub evaluators.
 
-Per step every slot is evaluated by ONE network -- the one whose side is searching (train.py:479-483) -- so a step costs
-one forward over the slots, split between the two models, not two.  With a process group the games are sharded over the
+Per step every slot is expanded from ONE network's output -- the one whose side is searching (train.py:479-483).  With the
+hand-written evaluators both models run over the whole slot batch (a few dozen games: the launches, not the FLOPs, are
+the cost) with the other model's requests masked out, and the merge happens on the device: a step has no host round trip.
+Dense-protocol evaluators (the stubs of the fixtures) are run on their own slots only.  With a process group the games are sharded over the
 ranks like self-play games (`distributed.shard_games`); the per-game results are all-gathered and every rank derives the
 same verdict from the same gathered table.
 """
@@ -58,11 +60,19 @@ def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_sim
             # choice follows the side to move of the real game, not of the evaluated position (train.py:479-483)
             red_to_move = eng.slot_ints[:, 0] == 1
             use_new = new_is_red == red_to_move
-            _evaluate_subset(eng, eval_new, x, use_new.nonzero().view(-1), policy_is_probs, dense, legal, value)
-            _evaluate_subset(eng, eval_old, x, (~use_new).nonzero().view(-1), policy_is_probs, dense, legal, value)
             if sparse:
+                # No host round trip in a step: each model runs over the whole (small) slot batch with the OTHER model's
+                # request counts masked to zero -- xq_policy_head_legal skips those rows -- and the two results are merged
+                # on the device.  Batch size and conv variant are the same every step (no nonzero(), no data-dependent shapes).
+                zero = torch.zeros_like(eng.req_counts)
+                ll_new, v_new = eval_new.evaluate_legal(x, eng.req_moves, torch.where(use_new, eng.req_counts, zero))
+                ll_old, v_old = eval_old.evaluate_legal(x, eng.req_moves, torch.where(use_new, zero, eng.req_counts))
+                torch.where(use_new.unsqueeze(1), ll_new, ll_old, out=legal)
+                torch.where(use_new, v_new.view(-1), v_old.view(-1), out=value)
                 eng.expand_legal(legal, value)
             else:
+                _evaluate_subset(eng, eval_new, x, use_new.nonzero().view(-1), policy_is_probs, dense, legal, value)
+                _evaluate_subset(eng, eval_old, x, (~use_new).nonzero().view(-1), policy_is_probs, dense, legal, value)
                 eng.expand(dense, value, policy_is_probs)
         st = eng.stats()
         if st["games_finished"] >= eval_games:

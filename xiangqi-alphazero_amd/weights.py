@@ -106,3 +106,41 @@ def make_state_dict(num_channels: int, num_res_blocks: int, seed: int = 0, polic
 
 # crc32 over make_state_dict_numpy(64, 3) in key order; pins the generator (fixtures depend on it)
 REFERENCE_CRC_64x3 = 0xE8FEBBD9
+
+
+def rescale_channels(sd, num_res_blocks: int, decades: float, seed: int = 0, big_channels: int = 0, big: float = 1.0e3):
+    """A function-preserving re-parameterisation of a `make_state_dict` result that spreads the activation scales, for the
+    numerical-margin test of the Winograd tower (tests/test_nn_fullsize.py): residual-stream channel c is multiplied by
+    S_c and every block's inner channel c by T_c^(i), S and T log-uniform over [10^-decades, 10^+decades] (`big_channels`
+    stream channels get S_c = `big` instead), by scaling the producing BatchNorm's weight and bias and dividing the
+    consuming convolution's input-channel weights.  ReLU is positively homogeneous and the skip connection adds equally
+    scaled channels, so in exact arithmetic the network's outputs do not change; in float32 the operand dynamic range of
+    every 3x3 convolution does.  Returns a new OrderedDict of torch tensors (float64 arithmetic, stored float32)."""
+    import torch
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    c = out["input_conv.0.weight"].shape[0]
+
+    def scales(tag):
+        u = _uniform("rescale." + tag, c, seed) * 2.0                     # [-1, 1)
+        return torch.from_numpy(10.0 ** (decades * u))
+
+    def scale_bn(prefix, f):
+        for k in (".weight", ".bias"):
+            out[prefix + k] = (out[prefix + k].double() * f).float()
+
+    def scale_in(key, f):                                                # divide the input-channel axis
+        out[key] = (out[key].double() / f.view(1, -1, 1, 1)).float()
+
+    s = scales("stream")
+    if big_channels > 0:
+        s[:big_channels] = big
+    scale_bn("input_conv.1", s)
+    for i in range(num_res_blocks):
+        t = scales("inner%d" % i)
+        scale_in(f"res_blocks.{i}.conv1.weight", s)
+        scale_bn(f"res_blocks.{i}.bn1", t)
+        scale_in(f"res_blocks.{i}.conv2.weight", t)
+        scale_bn(f"res_blocks.{i}.bn2", s)
+    scale_in("policy_head.0.weight", s)
+    scale_in("value_head.0.weight", s)
+    return out
