@@ -79,6 +79,10 @@ def parse_args():
     ap.add_argument("--graph", action="store_true",
                     help="time HIP-graph replays of the step (engine.capture_step) instead of eager launches; no per-stage breakdown")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--no-stagger", action="store_true",
+                    help="all slots start their searches together (no start_stagger): with --prewarm P every slot is P simulations into "
+                         "its first move when the timed steps start -- the counter passes use it with P = sims / 2, the mean of the "
+                         "steady-state mix, because a counter pass over the full staggered prewarm does not finish on this pool")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher / rendezvous / reduction rehearsal WITHOUT the GPU path: every rank reports fixed stand-in "
                          "numbers through the same collectives and the line is labelled a rehearsal with value null (CPU test "
@@ -152,6 +156,20 @@ class PseudoPolicy:
         return self.logits, self.value
 
 
+def profiler_region(resume: bool):
+    """XQ_BENCH_ROCTX=1 (set by tools/run_pmc_passes.sh): bracket the REAL steps with roctxProfilerResume / roctxProfilerPause so
+    that `rocprofv3 --selected-regions --pmc ...` collects counters for them only -- a counter pass over the ~3 500 launches of
+    the network-free prewarm does not finish on this pool.  No-op otherwise."""
+    if os.environ.get("XQ_BENCH_ROCTX") != "1":
+        return
+    import ctypes
+    lib = getattr(profiler_region, "_lib", None)
+    if lib is None:
+        lib = profiler_region._lib = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+        lib.roctxProfilerResume.argtypes = lib.roctxProfilerPause.argtypes = [ctypes.c_uint64]
+    (lib.roctxProfilerResume if resume else lib.roctxProfilerPause)(0)
+
+
 def measure(args, dev, rank, world, dist, backend, peaked):
     """One timed region: prewarm -> W warm-up steps -> barrier+sync, K steps, barrier+sync.  Returns the per-rank dict."""
     import torch
@@ -162,7 +180,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
     ev, ev_name = evaluator.make_evaluator(net, dev, args.evaluator)
     cfg = engine.make_config(args.games, args.sims, max_game_length=400, random_opening_moves=8,
                              temperature_threshold=20, enable_resign=True, seed=args.seed, rank=rank,   # "full" preset
-                             start_stagger=True)
+                             start_stagger=not args.no_stagger)
     eng = engine.SelfPlayEngine(cfg, dev, evaluator=ev)
     ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(4 * args.steps)]
     sparse = hasattr(ev, "evaluate_legal")
@@ -190,6 +208,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
                 eng.expand_legal(zero_legal, vl)
         torch.cuda.synchronize(dev)
         del pp
+    profiler_region(True)
     for _ in range(args.warmup):
         eng.step()
     sync()
@@ -225,6 +244,7 @@ def measure(args, dev, rank, world, dist, backend, peaked):
         e[3].record()
     sync()
     elapsed = time.perf_counter() - t0
+    profiler_region(False)
     if smi_thread is not None:
         smi_thread.join()
     s1 = eng.stats()
@@ -266,7 +286,7 @@ def reduce_ranks(m, dev, world, dist, backend):
     return max(float(p[0]) for p in parts), sum(float(p[1]) for p in parts), [float(p[1]) / float(p[0]) for p in parts]
 
 
-def tree_block(args, m):
+def tree_block(args, m, peaked=False):
     d = m["d"]
     sims = max(d["sims"], 1)
     evals = max(d["leaf_evals"] + d["root_evals"], 1)
@@ -280,7 +300,23 @@ def tree_block(args, m):
     roof = {}
     for name, nbytes, ms in (("k_select", sel_bytes, m["sel_ms"]), ("k_expand", exp_bytes, m["exp_ms"])):
         gbs = nbytes / args.steps / (ms * 1e-3) / 1e9
-        roof[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4)}
+        roof[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4),
+                      "algorithmic_bytes_per_launch": int(nbytes / args.steps), "traffic": None}
+    # HBM-side bytes per launch from the committed counter passes over the product path (tools/summarize_pmc_tree.py: real steps
+    # only, request-size counters); counters cannot be read from inside this process, so GB/s here = those bytes x this run's
+    # own launch time, and the ratio to the algorithmic bytes is the committed run's.
+    if m["sparse"] and args.games == 8192 and args.sims == 800:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_tree_kernels.json")))
+            v = [x for k, x in pmc["variants"].items() if k.startswith("peaked" if peaked else "near-uniform")][0]
+            for name, ms in (("k_select", m["sel_ms"]), ("k_expand", m["exp_ms"])):
+                t = v[name]["hbm_side_bytes_per_launch"]["total"]
+                roof[name]["traffic"] = t
+                roof[name]["traffic_over_algorithmic"] = v[name]["traffic_over_algorithmic"]
+                roof[name]["counter_GBps_at_this_runs_launch_time"] = round(t / (ms * 1e-3) / 1e9, 1)
+                roof[name]["traffic_source"] = "profiles/r03_pmc_tree_kernels.json (separate --pmc passes, sparse hand-off, real steps only)"
+        except Exception:
+            pass
     return tree, roof
 
 
@@ -422,7 +458,7 @@ def main():
         if roof is not None and args.games == 8192 and args.channels == 256:
             # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
             # WRITE_SIZE, separate runs of this same command): counters cannot be read from inside this process.
-            for f in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
                     fk = [v for k, v in pmc["FETCH_SIZE"].items() if "k_wino_conv" in k][0]["avg_KB_per_launch_raw"]
@@ -444,7 +480,7 @@ def main():
             roof["sclk_mhz_during_timed_steps"] = mhz
             roof["socket_power_w"] = m["smi"].get("power_w")
             roof["frac_of_peak_at_that_clock"] = round(roof["achieved"] / (PEAK_F32_MFMA * mhz / 2400.0), 4)
-        tree, tree_roof = tree_block(args, m)
+        tree, tree_roof = tree_block(args, m, args.peaked)
         value = sims_all / elapsed_max
         out = {
             "metric": "MCTS simulations/sec (whole node) + self-play games/hour, 256ch x 10blk ResNet",
@@ -454,7 +490,8 @@ def main():
             "config": {"workload": workload_label(args), "games_per_gpu": args.games, "sims_per_move": args.sims,
                        "net": "%dx%d" % (args.channels, args.blocks), "evaluator": m["ev_name"], "policy_handoff": "legal-move logits [G,128]" if m["sparse"] else "dense logits [G,8100]",
                        "launch": "HIP-graph replay, one launch per step" if m["graphed"] else "eager kernel launches",
-                       "prewarm_steps": m["prewarm"],
+                       "prewarm_steps": m["prewarm"], "slot_start": "together" if args.no_stagger else "staggered over one move",
+
                        "parallelism": "games sharded across ranks, no data-path collective"},
             "ranks": {"launched_by": "bench.py" if os.environ.get("XQ_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
                       "backend": backend if dist.is_initialized() else None, "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
@@ -464,7 +501,7 @@ def main():
             "tree": tree, "tree_roofline": tree_roof,
         }
         if mp is not None:
-            ptree, ptree_roof = tree_block(args, mp)
+            ptree, ptree_roof = tree_block(args, mp, True)
             out["peaked"] = {"workload": "same configuration, peaked-policy weights (weights.make_state_dict policy_gain 8; prewarm "
                                          "under a peaked pseudo-policy): deep, narrow trees",
                              "value": round(mp_sims / mp_el, 1), "unit": "simulations/s", "ms_per_step": round(1e3 * mp_el / args.steps, 3),

@@ -29,8 +29,9 @@ def main():
     for arg in sys.argv[1:]:
         counter, directory = arg.split("=", 1)
         out[counter] = summarise(directory, counter)
-    out["note"] = ("rocprofv3 --pmc <counter> --kernel-trace, one pass per counter, over `python3 bench.py --cpu-seconds 0 "
-                   "--steps 4 --warmup 2`; raw counter units (KB); FETCH_SIZE needs the gfx950 x2 correction for 16-B/lane reads")
+    out["note"] = ("rocprofv3 --pmc <counter> --kernel-trace, one pass per counter, over the bench command of tools/run_pmc_passes.sh "
+                   "(`python3 bench.py --steps 4 --warmup 2 --prewarm 300 --complete-games 0 --cpu-seconds 0`); raw counter units (KB); "
+                   "FETCH_SIZE needs the gfx950 x2 correction for 16-B/lane reads")
     json.dump(out, sys.stdout, indent=1)
 
 

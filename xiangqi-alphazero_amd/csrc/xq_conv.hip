@@ -54,25 +54,6 @@
 #define XQ_ABL 0
 #endif
 
-#ifndef XQ_STAMP
-#define XQ_STAMP 0
-#endif
-#ifndef XQ_PERSIST
-#define XQ_PERSIST 1          // wide variant: one workgroup per CU walks its tile groups (see k_wino_conv)
-#endif
-#ifndef XQ_TRICKLE
-#define XQ_TRICKLE 1          // persistent wide variant: a group's outputs wait in LDS and are stored during the next group's main loop
-#endif
-#ifndef XQ_EPI_OLD
-#define XQ_EPI_OLD 1          // 1: the wide variant with the exchange-plane epilogue (two 64-channel rounds); 0: the one-barrier distributed-reducer epilogue (A/B in DESIGN.md section 4.1)
-#endif
-#if XQ_STAMP
-// Diagnostic builds only (tests/microbench/conv_stamps.py): per-workgroup wall-clock stamps (100 MHz s_memrealtime) at
-// kernel entry, after the main loop, after the epilogue's last store was issued and after those stores completed, plus
-// the hardware id (XCC / SE / CU).  Written to a buffer no other code reads; never in the shipped library.
-__device__ unsigned long long g_xq_stamps[16384 * 8];
-#endif
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -99,18 +80,11 @@ constexpr int ESTR = 36;                             // floats per tile row of a
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
-// Wide variant's LDS: the one-barrier epilogue's exchange image [reducer wave][source slot][12 slices] of 1 KB (144 KB), or --
-// persistent form with deferred stores -- exchange planes of one 32-channel round (54 KB, over the staging buffers) and behind
-// them the finished outputs of the whole tile group (24 x 4 KB, thread-linear), which the NEXT group's main loop stores.
-constexpr int OUT_OFF = 4 * 3 * TILES * ESTR * 4;         // 55 296
-constexpr int LDS_BYTES_WIDE = OUT_OFF + 24 * 4096;        // 153 600 >= 147 456
+constexpr int LDS_BYTES_WIDE = 4 * 3 * TILES * (64 + 4) * 4;                        // exchange planes of a 64-channel round
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 // cache-policy variants (aux: bit 0 sc0, bit 1 nt, bit 4 sc1): weight fragments are read once per workgroup and never from
 // this CU's L1 again -- XQ_W_AUX selects how they pass through the caches
@@ -143,11 +117,6 @@ __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
 __device__ __forceinline__ float relu1(float x) {                // one v_max_f32 (fmaxf adds a canonicalising max)
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ float max1(float lo, float x) {      // one v_max_f32 against a wave-uniform bound
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(lo), "v"(x));
     return r;
 }
 __device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
@@ -183,41 +152,33 @@ __device__ __forceinline__ f32x4 pk_fms4(f32x4 x, f32x2 c, f32x4 y) {
 // two workgroups per CU (the round-1 shape).  NT = 4 ("wide"): 128 output channels per workgroup, 320 accumulators per
 // wave (VGPRs + AGPRs of the unified 512-entry file), ONE workgroup per CU: every staged input chunk and every transformed
 // A operand feeds twice as many MFMAs, and the input is fetched by half as many workgroups.
-// One tile group x one block of output channels: prologue, main loop, epilogue.  `rr` / `xcd` are the coordinates the
-// launch grid used to give one workgroup each (block rr * 8 + xcd); the persistent form of the wide variant walks rr.
 template <int NT>
-__device__ __forceinline__ void conv_group(const float *__restrict__ X, const float *__restrict__ Ug,
-                                           const float *__restrict__ bias, const float *__restrict__ R,
-                                           float *__restrict__ Y, int B, int C, int flags, int n_groups, int rr, int xcd,
-                                           char *lds, bool first_of_cu, unsigned &carry_off) {
+__global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float *__restrict__ X, const float *__restrict__ Ug,
+                                                   const float *__restrict__ bias, const float *__restrict__ R,
+                                                   float *__restrict__ Y, int B, int C, int flags, int n_groups) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Xr = lds;
-    // Deferred stores (persistent wide variant): the epilogue leaves the group's 24 output vectors per thread in LDS and
-    // returns their byte offset in `carry_off`; the main loop of the NEXT group stores one vector per chunk (a store issued
-    // every ~5000 cycles costs its issue slot; 24 back to back cost ~260 cycles each with four waves storing, and a wave
-    // blocked on a store issues no MFMA).  `carry_off` = 0xFFFFFFF0 (out of range: dropped by the hardware) when there is
-    // nothing to store.
-    constexpr bool TRK = NT == 4 && XQ_PERSIST && XQ_TRICKLE && XQ_EPI_OLD;
-    const unsigned carry_in = carry_off;
     constexpr int NCO = 32 * NT;                      // output channels per workgroup
     constexpr int UBUF_BYTES = 20 * 2 * NCO * 16;    // one 8-channel chunk of weights for them
     // Weight fragments per chunk, and fragment registers.  Narrow: 5 registers, each fragment fetched half a chunk (20 MFMAs)
     // ahead.  Wide: XQ_WIDE_POOL registers (default 16 of a chunk's 20): a fragment is fetched 16 fragments = 64 MFMAs = 4096
     // cycles ahead of its use.  Loads retire in order (vmcnt), so the wait for a weight fragment also waits for every OLDER
     // load -- including the staging loads of the raw input, a quarter of which miss to HBM (one 128-byte line serves four
-    // 8-channel chunks); with 10 registers they had 2560 cycles to land and every fourth chunk stalled (the in-situ ablation
-    // of round 3: staging 0.108 ms of 2.60, and the weight loads cost nothing once the staging loads are gone).  The slot of
-    // fragment f of chunk c is (20 c + f) mod POOL, so the code repeats every PER = lcm(20, POOL) / 20 chunks.
+    // 8-channel chunks); with 10 registers they had 2560 cycles to land (round 3's in-situ ablation: staging 0.108 ms of 2.60,
+    // and the weight loads cost nothing once the staging loads are gone).  16 registers: 2.528 against 2.551 ms; all 20: 2.563
+    // (profiles/r03_wino_ab_weight_pool_10_16_20.log).  The slot of fragment f of chunk c is (20 c + f) mod POOL, so the code
+    // repeats every PER = lcm(20, POOL) / 20 chunks.
 #ifndef XQ_WIDE_POOL
 #define XQ_WIDE_POOL 16
 #endif
-    constexpr int NF = 5 * NT, POOL = NT == 4 ? XQ_WIDE_POOL : NF / 2;
+    constexpr int NF = 5 * NT, POOL = NT == 4 ? XQ_WIDE_POOL : NF / 2;   // (narrow: 8 or 10 registers spill 124 / 32 VGPRs)
     constexpr int PER = NT == 4 ? (XQ_WIDE_POOL == 16 ? 4 : XQ_WIDE_POOL == 10 || XQ_WIDE_POOL == 20 ? 1 : -1) : 1;
     static_assert(PER > 0, "XQ_WIDE_POOL must be 10, 16 or 20");
 
     const int tid = threadIdx.x, lane = tid & 63, wp = tid >> 6;
-    const int wps = __builtin_amdgcn_readfirstlane(wp);          // the same number in an SGPR
     const int NG = C / NCO;
     const int per = 8 / NG;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     // ablation 2048 (C = 256): two weight slices per XCD, the two blocks that share a tile group back to back on it
     const int cog = (XQ_ABL & 2048) ? 2 * (xcd & 1) + (rr & 1) : xcd % NG;
     // flags bit 1: walk the batch back to front.  A launch that reads what the previous launch wrote (the next layer of
@@ -225,17 +186,6 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
     const int tg_fwd = (XQ_ABL & 2048) ? (rr >> 1) * 4 + (xcd >> 1) : rr * per + xcd / NG;
     const int tg = (flags & 2) ? n_groups - 1 - tg_fwd : tg_fwd;
     if (tg_fwd >= n_groups) return;
-#if XQ_STAMP
-    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), sm0 = __builtin_amdgcn_s_memtime();
-#endif
-    // flags bit 3 (XQ_CONV_STAGGER): the first workgroup of every CU (the first 256 blocks of the grid are dealt one per CU)
-    // waits for one of 16 phases of `stagger_ticks` x 10 ns.  Equal workgroups otherwise run in lockstep on all 256 CUs, and
-    // so do their epilogues: every round ends in one chip-wide burst of residual reads and output writes at the HBM's
-    // bandwidth while the HBM idles during the main loops.  A CU keeps the phase it starts with for the rest of the launch.
-    if ((flags & 8) && first_of_cu) {
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((rr * 5) & 15) * (unsigned)(flags >> 8);
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
-    }
     const int relu = flags & 1;
     const int T = B * 15;
     const int t0 = tg * TILES;
@@ -304,14 +254,9 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
     f32x4 a[5], ub[POOL];
     auto loop_barrier = [&]() __attribute__((always_inline)) { if (!(XQ_ABL & 16)) __syncthreads(); };
     // weight fragment f of a chunk: (q, nt) = (QO[f >> 1], f & 1), processing order of the column frequencies 1,2,3,0,4
-    // Wide variant: wave w's LOCAL N-tile k is the workgroup's N-tile (k + w + 1) & 3, so that the N-tile a wave reduces in
-    // the epilogue (its own number w) is always local tile 3 -- the one whose accumulators are pinned to VGPRs.
-    unsigned ntoff[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) ntoff[k] = (NT == 4 && !XQ_EPI_OLD ? ((k + wps + 1) & 3) : k) * (32 * 16);
     auto load_frag = [&](int chunk, int f, int slot) __attribute__((always_inline)) {
         const int q = (f / NT) == 0 ? 1 : (f / NT) == 1 ? 2 : (f / NT) == 2 ? 3 : (f / NT) == 3 ? 0 : 4;
-        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + ntoff[f % NT]);
+        ub[slot] = buf_ld4_w(urs, ul, ((XQ_ABL & 1024) ? 0u : (unsigned)chunk * UBUF_BYTES) + q * (2 * NCO * 16) + (f % NT) * (32 * 16));
     };
     auto transform0 = [&]() __attribute__((always_inline)) {
         f32x4 w[5];
@@ -325,14 +270,11 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
         a[4] = pk_fma4(t, mtwo, pk_sub4(w[4], w[2]));
     };
     // One chunk: 40 MFMAs (10 weight fragments x 4 k-steps); the transform of the next chunk is threaded through.
-    const __amdgpu_buffer_rsrc_t yrs_t = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, (int)((unsigned)B * 90u * (unsigned)C * 4u), 0x00020000);
     auto chunk_body = [&](int nchunk_u, int lchunk, auto xo_tag, int stage, auto first_tag, auto ph_tag) __attribute__((always_inline)) {
         constexpr int XO = decltype(xo_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int PH = decltype(ph_tag)::value;        // chunk index mod PER
-        f32x4 d1, d2, w1, w3, w2, w0, t, e, fm, v0, tv;
-        const int tslot = lchunk - 2;                       // deferred store of chunks 2 .. 25: output vector lchunk - 2
-        const int tsc = tslot < 0 ? 0 : tslot > 23 ? 23 : tslot;
+        f32x4 d1, d2, w1, w3, w2, w0, t, e, fm, v0;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const int g = f / NT, nt = f % NT;
@@ -340,7 +282,6 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
             const int col = g == 0 ? 1 : g == 1 ? 3 : g == 2 ? 2 : g == 3 ? 0 : 4;
             const int slot = (NF * PH + f) % POOL;
             if (nt == 0 && !(XQ_ABL & 2)) { d1 = ld4(Xr + tb1 + XO + col * XSTRIDE); d2 = ld4(Xr + tb2 + XO + col * XSTRIDE); }
-            if (TRK && f == 0) tv = ld4(lds + OUT_OFF + tsc * 4096 + tid * 16);
             if (!(XQ_ABL & 6)) {
                 if (f == 3 * NT) a[3] = t;                            // column frequency 3 retired with the last fragment of group 2
                 if (f == 4 * NT) a[0] = v0;
@@ -350,27 +291,13 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
                 if (XQ_ABL & 64) {
                     if (FIRST && jj == 0) for (int e = 0; e < 16; ++e) acc[q][nt][e] = 0.0f;
                     asm volatile("" ::"v"(a[q][jj]), "v"(ub[slot][jj]));
-                } else if (NT == 4 && !XQ_EPI_OLD) {
-                    // Wide variant: the WEIGHTS are the MFMA's A operand (rows = output channels) and the transformed input its
-                    // B operand (columns = tiles): a lane then holds FOUR CONSECUTIVE CHANNELS of one tile in every register
-                    // quad of an accumulator, which is what lets the epilogue exchange and store 16 bytes per lane.  Same
-                    // products, same k order: the results are bit-identical to the narrow variant's.
-                    if (FIRST && jj == 0) {
-                        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[slot][jj], a[q][jj], zero, 0, 0, 0);
-                    } else if (nt == 3) {
-                        // 20 accumulator tiles do not fit the 256 AGPRs; the compiler would spill four of them around the
-                        // loop.  The five tiles of local N-tile 3 are pinned to VGPRs ("+v"), the other 15 stay in AGPRs.
-                        // (A dependent MFMA on its own vDst/SrcC needs no software wait states; the first VALU read of these
-                        // registers is fenced in the epilogue.)
-                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(ub[slot][jj]), "v"(a[q][jj]));
-                    } else {
-                        acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[slot][jj], a[q][jj], acc[q][nt], 0, 0, 0);
-                    }
                 } else if (FIRST && jj == 0) {
                     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], zero, 0, 0, 0);
                 } else if (NT == 4 && nt == 3) {
+                    // wide variant: 20 accumulator tiles do not fit the 256 AGPRs; the compiler would spill four of them
+                    // around the loop.  The five tiles of the last N-tile are pinned to VGPRs ("+v"), the other 15 stay in
+                    // AGPRs.  (A dependent MFMA on its own vDst/SrcC needs no software wait states.)
                     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[q][jj]), "v"(ub[slot][jj]));
                 } else {
                     acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][jj], ub[slot][jj], acc[q][nt], 0, 0, 0);
@@ -388,11 +315,6 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
                 if (g == 0) {
                     w1 = rowpair(d1, d2);
                     if ((XQ_ABL & 512) && stage >= 0) { store_x(stage); load_x(stage + 1); }
-                    if (TRK) {
-                        const int rd_ = tsc / 6, it_ = tsc - 6 * rd_;
-                        const unsigned soff = (unsigned)(32 * rd_ + ((it_ / 3) * 9 + it_ % 3) * C) * 4u;
-                        buf_st4(yrs_t, tslot == tsc ? carry_in : 0xFFFFFFF0u, soff, tv);
-                    }
                 }
                 if (g == 1) { w3 = rowpair(d1, d2); t = pk_sub4(w3, w1); e = pk_fma4(w1, two, w3); fm = pk_fms4(w1, two, w3); }
                 if (g == 2) { w2 = rowpair(d1, d2); a[1] = pk_add4(fm, w2); a[2] = pk_fms4(w2, three, e); }
@@ -425,9 +347,6 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
     __syncthreads();
     transform0();
     __syncthreads();                                  // chunk 0 stores into the buffer transform0 just read
-#if XQ_STAMP
-    const unsigned long long stp = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // ---- main loop: chunk c multiplies (a, fragments) of chunk c, transforms chunk c+1 out of buffer (c+1)&1,
     // stores chunk c+2 into buffer c&1 and fetches chunk c+3; one barrier per chunk
@@ -460,9 +379,6 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
             loop_barrier();
         }
     }
-#if XQ_STAMP
-    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime(), sm1 = __builtin_amdgcn_s_memtime();
-#endif
     if (XQ_ABL & 32) {                                 // ablation: no epilogue (keep the accumulators observable)
         float sacc = 0.0f;
         for (int q = 0; q < 5; ++q) for (int n = 0; n < NT; ++n) for (int e = 0; e < 16; ++e) sacc += acc[q][n][e];
@@ -470,135 +386,12 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
         return;
     }
 
-    if constexpr (NT == 4 && !XQ_EPI_OLD) {
-        // ---- wide epilogue: Y = A_r^T M A_c, bias, residual, ReLU with ONE barrier ------------------------------------------
-        // Lane (tile l31, half h) holds, in register quad i of accumulator (q, k), channels 8 i + 4 h .. + 3 of local N-tile k
-        // for ITS tile.  Each wave finishes the column half of the inverse transform in registers (5 frequencies -> 3 output
-        // columns), keeps local N-tile 3 (= the workgroup's N-tile `wave number`) and hands the other three to the waves
-        // that reduce them: wave r sums the four Winograd rows of N-tile r.  Exchange image: [reducer r][slot s][slice 3 i + b]
-        // of 1 KB, lane-linear (16 bytes per lane: every ds_write_b128 / ds_read_b128 is conflict-free), slot s of reducer r
-        // = source wave (r + 1 + s) & 3; 4 x 3 x 12 KB = 144 KB over the staging buffers, which nobody reads after the main
-        // loop's last barrier.  Stores and residual loads go through buffer descriptors: lanes of tiles past the end carry
-        // an out-of-range offset and are dropped by the hardware (no divergent branches).
-        // Everything the epilogue needs per lane is recomputed from the lane number (mbcnt, so that nothing of it is kept
-        // alive -- or spilled -- across the main loop).
-        const int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const int eh = elane >> 5, el31 = elane & 31;
-        const int Cs = __builtin_amdgcn_readfirstlane(C);            // keeps every scalar offset below in an SGPR (no waterfall loops)
-        const int eg = t0 + el31, egc = eg < T ? eg : T - 1;
-        const int ebd = egc / 15, et2 = egc - ebd * 15, ety = et2 / 3, etx = et2 - ety * 3;
-        const unsigned ooff_in = (unsigned)(((ebd * 90 + 2 * ety * 9 + 3 * etx) * Cs + cog * NCO + 32 * wps + 4 * eh) * 4);
-        const unsigned ooff = eg < T ? ooff_in : 0xFFFFFFF0u;
-        const unsigned nbytes = (unsigned)B * 90u * (unsigned)C * 4u;
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, (int)nbytes, 0x00020000);
-        // no residual: a descriptor of zero records -- every load returns 0.0f without touching memory, one code path
-        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(R != nullptr ? R : X), 0, R != nullptr ? (int)nbytes : 0, 0x00020000);
-        f32x4 rv[2][3][4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4 *)(bias + cog * NCO + 32 * wps + 8 * i + 4 * eh);
-#pragma unroll
-        for (int ya = 0; ya < 2; ++ya)
-#pragma unroll
-            for (int yb = 0; yb < 3; ++yb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rv[ya][yb][i] = buf_ld4(rrs, ooff, (unsigned)((ya * 9 + yb) * Cs + 8 * i) * 4u);
-        const float rlo = relu ? 0.0f : -__builtin_inff();            // ReLU or identity as one v_max_f32, no branch
-        // the "+v" MFMAs of local N-tile 3 are invisible to the compiler's hazard recogniser: fence the first VALU read of
-        // the last one's destination by its 16 passes (the other four tiles' last MFMAs are >= 256 cycles older)
+    if constexpr (NT == 4) {
+        // The "+v" MFMAs of N-tile 3 are invisible to the compiler's hazard recogniser: hold the first VALU read of the last
+        // one's destination for its 16 passes (the other four tiles' last MFMAs are >= 256 cycles older).  Costs 64 cycles
+        // per workgroup; the narrow == wide bit-identity test (tests/test_nn_parity.py) stays the functional guard.
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[4][3]));
-        // column half on register pairs (packed fp32): y0 = m0+m1+m2+m3, y1 = m1-m2+2 m3, y2 = m1+m2+4 m3+m4
-        auto coltr = [&](int k, int i, f32x4 (&y)[3]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const int e = 4 * i + 2 * e2;
-                const f32x2 m0 = {acc[0][k][e], acc[0][k][e + 1]}, m1 = {acc[1][k][e], acc[1][k][e + 1]};
-                const f32x2 m2 = {acc[2][k][e], acc[2][k][e + 1]}, m3 = {acc[3][k][e], acc[3][k][e + 1]};
-                const f32x2 m4 = {acc[4][k][e], acc[4][k][e + 1]};
-                const f32x2 s12 = pk_add2(m1, m2);
-                const f32x2 y0 = pk_add2(pk_add2(m0, m3), s12);
-                const f32x2 y1 = pk_fma2(m3, two, pk_sub2(m1, m2));
-                const f32x2 y2 = pk_add2(pk_fma2(m3, four, s12), m4);
-                y[0][2 * e2] = y0[0]; y[0][2 * e2 + 1] = y0[1];
-                y[1][2 * e2] = y1[0]; y[1][2 * e2 + 1] = y1[1];
-                y[2][2 * e2] = y2[0]; y[2][2 * e2 + 1] = y2[1];
-            }
-        };
-        // Slice by slice -- the 20 accumulator values of (k, i), 14 packed operations, 3 writes -- with a scheduling fence after
-        // each slice: left alone, the compiler reads all 240 AGPRs first (the LDS write path then idles for 1 500 cycles and
-        // the residual is pushed out to AGPRs and read back); fed steadily, the 144 KB of writes (79 bytes per clock per CU)
-        // drain beside the column transform.
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            char *dst = lds + ((((wps + k + 1) & 3) * 3 + (2 - k)) * 12) * 1024 + elane * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 y[3];
-                coltr(k, i, y);
-#pragma unroll
-                for (int yb = 0; yb < 3; ++yb) *(f32x4 *)(dst + (3 * i + yb) * 1024) = y[yb];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        f32x4 own[4][3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) coltr(3, i, own[i]);
-#if XQ_STAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long sb = __builtin_amdgcn_s_memrealtime();
-#endif
-        __syncthreads();
-#if XQ_STAMP
-        const unsigned long long sc = __builtin_amdgcn_s_memrealtime();
-#endif
-        // row half: Y[0] = (M0 + M1) + M2, Y[1] = (M1 - M2) - M3 (the narrow variant's order), M_p from wave p.  The three
-        // foreign contributions of slice it + 1 are read while slice it is finished and stored (two stores per ~30 vector
-        // instructions: the store path takes ~150 cycles per wave instruction with four waves storing).
-        const char *src = lds + (wps * 3 * 12) * 1024 + elane * 16;
-        auto finish = [&](auto r_tag) __attribute__((always_inline)) {
-            constexpr int RR = decltype(r_tag)::value;
-            f32x4 nx[3];
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) nx[sl] = *(const f32x4 *)(src + (sl * 12) * 1024);
-#pragma unroll
-            for (int it = 0; it < 12; ++it) {
-                const int i = it / 3, yb = it % 3;
-                f32x4 m[4];
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) m[(RR + 1 + sl) & 3] = nx[sl];
-                m[RR] = own[i][yb];
-                if (it + 1 < 12) {
-#pragma unroll
-                    for (int sl = 0; sl < 3; ++sl) nx[sl] = *(const f32x4 *)(src + (sl * 12 + it + 1) * 1024);
-                }
-                f32x4 y0 = pk_add4(pk_add4(m[0], m[1]), m[2]), y1 = pk_sub4(pk_sub4(m[1], m[2]), m[3]);
-                y0 = pk_add4(pk_add4(y0, bv[i]), rv[0][yb][i]);
-                y1 = pk_add4(pk_add4(y1, bv[i]), rv[1][yb][i]);
-                y0.x = max1(rlo, y0.x); y0.y = max1(rlo, y0.y); y0.z = max1(rlo, y0.z); y0.w = max1(rlo, y0.w);
-                y1.x = max1(rlo, y1.x); y1.y = max1(rlo, y1.y); y1.z = max1(rlo, y1.z); y1.w = max1(rlo, y1.w);
-                buf_st4(yrs, ooff, (unsigned)(yb * Cs + 8 * i) * 4u, y0);
-                buf_st4(yrs, ooff, (unsigned)((9 + yb) * Cs + 8 * i) * 4u, y1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (wps == 0) finish(std::integral_constant<int, 0>{});
-        else if (wps == 1) finish(std::integral_constant<int, 1>{});
-        else if (wps == 2) finish(std::integral_constant<int, 2>{});
-        else finish(std::integral_constant<int, 3>{});
-#if XQ_STAMP
-        {
-            const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
-            if (tid == 0) {
-                unsigned long long *o = g_xq_stamps + (size_t)((rr * 8 + xcd) & 16383) * 8;
-                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
-                o[4] = sb; o[5] = sc; o[6] = sm0; o[7] = (sm1 << 20) | (stp - st0);
-            }
-        }
-#endif
-        return;
     }
-
     // ---- epilogue: Y = A_r^T M A_c, bias, residual, ReLU; one 32-channel half at a time through LDS --------------
     // Thread (tile = tid >> 3, channel quad = tid & 7) writes the six pixels of its tile, so the pixel inside the tile is
     // a compile-time constant of the unrolled loop.  The residual loads come first: their HBM latency hides behind the
@@ -614,7 +407,7 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
     // over the staging buffers, a second barrier before they are rewritten.  Wide variant (alone on its CU: every
     // dependent LDS round trip is exposed, and the LDS is all its own): RW = 2 -- two rounds instead of four
     // (104 KB of planes).  Residual loads run one round ahead.
-    constexpr int RW = (NT == 4 && !TRK) ? 2 : 1, ROUNDS = NT / RW;
+    constexpr int RW = NT == 4 ? 2 : 1, ROUNDS = NT / RW;
     constexpr int ESTR_R = 32 * RW + 4;               // floats per tile row of a plane
     constexpr int ESET = 4 * 3 * TILES * ESTR_R;     // floats per plane set
     constexpr bool E2 = false;                        // two 64-channel plane sets (209 KB) do not fit the CU's 160 KB
@@ -674,10 +467,7 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
                 if (relu) { y.x = relu1(y.x); y.y = relu1(y.y); y.z = relu1(y.z); y.w = relu1(y.w); }
                 yv[it] = y;
             }
-            if (TRK) {
-#pragma unroll
-                for (int it = 0; it < 6; ++it) *(f32x4 *)(lds + OUT_OFF + (n * 6 + it) * 4096 + tid * 16) = yv[it];
-            } else if (eok) {
+            if (eok) {
 #pragma unroll
                 for (int it = 0; it < 6; ++it) st4_y(Y + obase + 32 * n + ((it / 3) * 9 + it % 3) * C, yv[it]);
             }
@@ -689,55 +479,9 @@ __device__ __forceinline__ void conv_group(const float *__restrict__ X, const fl
         }
         if (rd + 1 < ROUNDS && !E2) __syncthreads();  // the next round overwrites the planes
     }
-    if (TRK) carry_off = eok ? (unsigned)obase * 4u : 0xFFFFFFF0u;
-#if XQ_STAMP
-    {
-        const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            unsigned long long *o = g_xq_stamps + (size_t)((rr * 8 + xcd) & 16383) * 8;
-            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st1; o[5] = st1; o[6] = sm0; o[7] = (sm1 << 20) | (stp - st0);
-        }
-    }
-#endif
-}
-
-// XQ_PERSIST (wide variant): ONE workgroup per CU walks its tile groups (block b of the launch takes the groups the grid
-// form gave to blocks b, b + grid, b + 2 grid, ...: same XCD, same weight slice) instead of one workgroup per group.
-template <int NT>
-__global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float *__restrict__ X, const float *__restrict__ Ug,
-                                                   const float *__restrict__ bias, const float *__restrict__ R,
-                                                   float *__restrict__ Y, int B, int C, int flags, int n_groups) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int xcd = blockIdx.x & 7;
-    const int per = 8 / (C / (32 * NT)), NG = C / (32 * NT);
-    unsigned carry = 0xFFFFFFF0u;
-    if (NT == 4 && XQ_PERSIST) {
-        const int step = gridDim.x >> 3;
-        for (int rr = blockIdx.x >> 3; rr * per + xcd / NG < n_groups; rr += step) {
-            conv_group<NT>(X, Ug, bias, R, Y, B, C, flags, n_groups, rr, xcd, lds, rr == (int)(blockIdx.x >> 3), carry);
-            __syncthreads();                            // the next group's prologue rewrites the LDS the epilogue read
-        }
-        if (XQ_TRICKLE && XQ_EPI_OLD) {                 // the last group's outputs: every thread stores its own 24 vectors
-            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, (int)((unsigned)B * 90u * (unsigned)C * 4u), 0x00020000);
-#pragma unroll
-            for (int sl = 0; sl < 24; ++sl)
-                buf_st4(yrs, carry, (unsigned)(32 * (sl / 6) + (((sl % 6) / 3) * 9 + (sl % 6) % 3) * C) * 4u,
-                        ld4(lds + OUT_OFF + sl * 4096 + (int)threadIdx.x * 16));
-        }
-    } else {
-        conv_group<NT>(X, Ug, bias, R, Y, B, C, flags, n_groups, blockIdx.x >> 3, xcd, lds, blockIdx.x < 256, carry);
-    }
 }
 
 }  // namespace
-
-#if XQ_STAMP
-extern "C" int xq_debug_read_stamps(unsigned long long *host, int n_blocks) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xq_stamps), (size_t)n_blocks * 8 * sizeof(unsigned long long));
-}
-#endif
 
 extern "C" {
 
@@ -763,21 +507,10 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     const int lds_bytes = (XQ_ABL & 65536) ? 100 * 1024 : LDS_BYTES;      // ablation: one workgroup per CU
     const int per = 8 / (channels / nco);
     const int rows = (n_groups + per - 1) / per;
-    if (wide) {
-        int grid = rows * 8;
-        if (XQ_PERSIST) {
-            static thread_local int cus8 = 0;               // CUs of the current device, rounded down to whole XCD rows
-            if (!cus8) {
-                int dev = 0, cus = 0;
-                XQ_TRY(hipGetDevice(&dev));
-                XQ_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-                cus8 = cus >= 8 ? (cus / 8) * 8 : 8;
-            }
-            if (grid > cus8) grid = cus8;
-        }
-        hipLaunchKernelGGL(k_wino_conv<4>, dim3(grid), dim3(256), LDS_BYTES_WIDE, (hipStream_t)stream, dev_x, dev_u, dev_bias,
+    if (wide)
+        hipLaunchKernelGGL(k_wino_conv<4>, dim3(rows * 8), dim3(256), LDS_BYTES_WIDE, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
-    } else
+    else
         hipLaunchKernelGGL(k_wino_conv<2>, dim3(rows * 8), dim3(256), lds_bytes, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
     return xq::launch_status();
