@@ -76,15 +76,28 @@ constexpr int XU_ODD = 10, XU_PAIR = 25, XU_B = 157;
 constexpr int XPLANE = (4 * XU_B) * 16;             // 4 boards per plane
 constexpr int XDUMP = 4 * XU_B - 1;                 // a unit no tile reads: target of out-of-range staging lanes
 constexpr int XRAW = 2 * XPLANE;
-constexpr int ESTR = 36;                             // floats per tile row of an exchange plane (32 + 4: the two
+// Row stride of an exchange plane: the epilogue's reader (tile = tid >> 3, channel quad = tid & 7) issues ds_read_b128 in the
+// lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: four tiles x a 16-float window each.  With a stride == 32 mod 64
+// floats the four windows fall on four disjoint quarters of the 64 banks (round 2's 36 / 68 gave 2-3-way conflicts:
+// SQ_LDS_BANK_CONFLICT 1.7e7 per launch).  The writes are ds_write_b32 of 32 consecutive floats: any stride.
+#ifndef XQ_EPAD_WIDE
+#define XQ_EPAD_WIDE 32
+#endif
+#ifndef XQ_EPAD_NARROW
+#define XQ_EPAD_NARROW 0
+#endif
+constexpr int ESTR = 32 + XQ_EPAD_NARROW;                             // floats per tile row of an exchange plane (32 + 4: the two
                                                      // lane halves of an accumulator write land on different banks)
 constexpr int E_BYTES = 4 * 3 * TILES * ESTR * 4;  // epilogue exchange for one 32-channel half: [row p][b][tile][co]
 constexpr int LDS_BYTES = 2 * XRAW > E_BYTES ? 2 * XRAW : E_BYTES;
-constexpr int LDS_BYTES_WIDE = 4 * 3 * TILES * (64 + 4) * 4;                        // exchange planes of a 64-channel round
+constexpr int LDS_BYTES_WIDE = 4 * 3 * TILES * (64 + XQ_EPAD_WIDE) * 4;             // exchange planes of a 64-channel round
 
 __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 // cache-policy variants (aux: bit 0 sc0, bit 1 nt, bit 4 sc1): weight fragments are read once per workgroup and never from
 // this CU's L1 again -- XQ_W_AUX selects how they pass through the caches
@@ -117,6 +130,11 @@ __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
 __device__ __forceinline__ float relu1(float x) {                // one v_max_f32 (fmaxf adds a canonicalising max)
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float max1(float lo, float x) {      // one v_max_f32 against a wave-uniform bound
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(lo), "v"(x));
     return r;
 }
 __device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
@@ -392,6 +410,95 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         // per workgroup; the narrow == wide bit-identity test (tests/test_nn_parity.py) stays the functional guard.
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[4][3]));
     }
+#ifndef XQ_EPI_PIPE
+#define XQ_EPI_PIPE 1
+#endif
+    if constexpr (NT == 4 && XQ_EPI_PIPE) {
+        // ---- wide epilogue, software-pipelined against its own stores ------------------------------------------------------
+        // Same exchange as below (two rounds of 64 channels through the planes, thread (tile, channel quad) finishes six
+        // pixels), re-ordered around one measured fact: a 1-KB store instruction takes the CU's store path ~260 cycles with four
+        // waves storing, and a wave whose store finds the queue full issues NOTHING meanwhile -- 24 stores back to back are
+        // ~3 us of a 6.6 us epilogue (profiles/r03_instruction_costs_one_wave_per_simd.log).  So the twelve output vectors of
+        // round 0 are kept in registers and stored one by one between the segments of round 1's column transform (16 segments
+        // of ~20 vector instructions), round 1's are stored as each is finished, and the next round's residual loads are
+        // issued one per finished vector.  Scheduling fences keep the compiler from re-clustering them.  No divergent branch:
+        // lanes of tiles past the end carry an out-of-range buffer offset (dropped by the hardware), a null residual is a
+        // descriptor of zero records (loads return 0.0f), ReLU-or-identity is one v_max_f32 against 0 / -inf.
+        const int etile = tid >> 3, co = (tid & 7) * 4;
+        const int eg = t0 + etile, egc = eg < T ? eg : T - 1;
+        const int ebd = egc / 15, et2 = egc - ebd * 15, ety = et2 / 3, etx = et2 - ety * 3;
+        const int Cs = __builtin_amdgcn_readfirstlane(C);
+        const unsigned ooff_in = (unsigned)(((ebd * 90 + 2 * ety * 9 + 3 * etx) * Cs + cog * NCO + co) * 4);
+        const unsigned ooff = eg < T ? ooff_in : 0xFFFFFFF0u;
+        const unsigned nbytes = (unsigned)B * 90u * (unsigned)C * 4u;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, (int)nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(R != nullptr ? R : X), 0, R != nullptr ? (int)nbytes : 0, 0x00020000);
+        const float rlo = relu ? 0.0f : -__builtin_inff();
+        constexpr int ESTR_R = 64 + XQ_EPAD_WIDE;
+        auto goff = [&](int n, int it) __attribute__((always_inline)) { return (unsigned)(32 * n + ((it / 3) * 9 + it % 3) * Cs) * 4u; };
+        f32x4 resv[2][6], bv[4], pend[12];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int it = 0; it < 6; ++it) resv[s][it] = buf_ld4(rrs, ooff, goff(s, it));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bv[n] = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
+        float *E = (float *)lds;
+        float *ew = E + ((wp * 3) * TILES + 4 * h) * ESTR_R + l31;
+        const float *er = E + etile * ESTR_R + co;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int n = rd * 2 + s;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 m0 = {acc[0][n][e], acc[0][n][e + 1]}, m1 = {acc[1][n][e], acc[1][n][e + 1]};
+                    const f32x2 m2 = {acc[2][n][e], acc[2][n][e + 1]}, m3 = {acc[3][n][e], acc[3][n][e + 1]};
+                    const f32x2 m4 = {acc[4][n][e], acc[4][n][e + 1]};
+                    const f32x2 s12 = pk_add2(m1, m2);
+                    const f32x2 y0 = pk_add2(pk_add2(m0, m3), s12);
+                    const f32x2 y1 = pk_fma2(m3, two, pk_sub2(m1, m2));
+                    const f32x2 y2 = pk_add2(pk_fma2(m3, four, s12), m4);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int tile = ((e + k) & 3) + 8 * ((e + k) >> 2);     // + 4 h (in ew)
+                        ew[(0 * TILES + tile) * ESTR_R + 32 * s] = y0[k];
+                        ew[(1 * TILES + tile) * ESTR_R + 32 * s] = y1[k];
+                        ew[(2 * TILES + tile) * ESTR_R + 32 * s] = y2[k];
+                    }
+                    const int seg = s * 8 + e / 2;                               // 0 .. 15
+                    if (rd == 1 && seg < 12) buf_st4(yrs, ooff, goff(seg / 6, seg % 6), pend[seg]);   // round 0's vector `seg`
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int n = rd * 2 + s;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int ya = it / 3, yb = it % 3;
+                    const float *e0 = er + yb * TILES * ESTR_R + 32 * s;
+                    const int pstride = 3 * TILES * ESTR_R;      // next Winograd row p
+                    f32x4 y;
+                    if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
+                    else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
+                    y = y + bv[n] + resv[s][it];
+                    y.x = max1(rlo, y.x); y.y = max1(rlo, y.y); y.z = max1(rlo, y.z); y.w = max1(rlo, y.w);
+                    if (rd == 0) {
+                        pend[s * 6 + it] = y;
+                        resv[s][it] = buf_ld4(rrs, ooff, goff(2 + s, it));      // round 1's residual, one per finished vector
+                    } else {
+                        buf_st4(yrs, ooff, goff(n, it), y);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (rd == 0) __syncthreads();             // round 1 overwrites the planes
+        }
+        return;
+    }
     // ---- epilogue: Y = A_r^T M A_c, bias, residual, ReLU; one 32-channel half at a time through LDS --------------
     // Thread (tile = tid >> 3, channel quad = tid & 7) writes the six pixels of its tile, so the pixel inside the tile is
     // a compile-time constant of the unrolled loop.  The residual loads come first: their HBM latency hides behind the
@@ -408,7 +515,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     // dependent LDS round trip is exposed, and the LDS is all its own): RW = 2 -- two rounds instead of four
     // (104 KB of planes).  Residual loads run one round ahead.
     constexpr int RW = NT == 4 ? 2 : 1, ROUNDS = NT / RW;
-    constexpr int ESTR_R = 32 * RW + 4;               // floats per tile row of a plane
+    constexpr int ESTR_R = RW == 2 ? 64 + XQ_EPAD_WIDE : ESTR;     // floats per tile row of a plane
     constexpr int ESET = 4 * 3 * TILES * ESTR_R;     // floats per plane set
     constexpr bool E2 = false;                        // two 64-channel plane sets (209 KB) do not fit the CU's 160 KB
     f32x4 resv[RW][6];
