@@ -121,6 +121,54 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long *out, float *sink
     if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+// fp32 MFMA stream (one wave per SIMD, 32 MFMAs per iteration on 8 accumulators) with R ds_read_b128 per iteration issued by
+// the waves selected by `readers` (bit w = wave w reads): what does an LDS read cost the MFMA stream of the wave that issues it,
+// alone and with the other three waves reading at the same time?
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int R>
+__global__ __launch_bounds__(256, 1) void kmf(unsigned long long *out, float *sink, int readers, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = tid * 0.001f, b = 1.0f + lane * 0.01f;
+    f32x4 t = {0, 0, 0, 0};
+    for (int o = tid * 16; o < 147456; o += 4096) *(f32x4 *)(lds + o) = f32x4{a, b, a, b};
+    __syncthreads();
+    const bool rd = (readers >> wave) & 1;
+    const char *lp = lds + wave * 36864 + lane * 16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i & 7], 0, 0, 0);
+            if (R > 0 && rd && (i % (32 / R)) == 0) t += *(const f32x4 *)(lp + (i / (32 / R)) * 1024);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = t.x + t.y + t.z + t.w;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][5];
+    if (s == 1234.5f) sink[tid] = s;
+    if (lane == 0) out[blockIdx.x * 4 + wave] = (t1 - t0) / iters;
+}
+template <int R>
+static void run_mf(const char *name, int readers) {
+    unsigned long long *d;
+    float *sink;
+    hipMalloc(&d, 256 * 4 * 8);
+    hipMalloc(&sink, 4096);
+    hipFuncSetAttribute((const void *)kmf<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(kmf<R>, dim3(256), dim3(256), 150 * 1024, 0, d, sink, readers, 200);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(1024);
+    hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> w0, w3;
+    for (int b = 0; b < 256; ++b) { w0.push_back(h[b * 4]); w3.push_back(h[b * 4 + 3]); }
+    std::sort(w0.begin(), w0.end()); std::sort(w3.begin(), w3.end());
+    printf("%-70s wave 0: %6llu  wave 3: %6llu  cycles per 32 MFMAs (2048 = MFMA only)\n", name, w0[128], w3[128]);
+    hipFree(d); hipFree(sink);
+}
+
 template <int KIND>
 static void run(const char *name, int per_iter, int active_mod = 1) {
     unsigned long long *d;
@@ -161,5 +209,12 @@ int main() {
     run<11>("store dwordx4, 8 lanes per line, 1 CU in 32 active", 4, 32);
     run<13>("load  dwordx4, 8 lanes per line, 1 CU in 8 active", 4, 8);
     run<6>("ds_write_b128 lane-linear, 1 CU in 8 active", 8, 8);
+    run_mf<0>("MFMA x32 per iteration, no LDS reads", 0);
+    run_mf<8>("MFMA x32 + 8 ds_read_b128 per iteration, ALL four waves read", 15);
+    run_mf<8>("MFMA x32 + 8 ds_read_b128 per iteration, ONLY wave 0 reads", 1);
+    run_mf<4>("MFMA x32 + 4 ds_read_b128 per iteration, ALL four waves read", 15);
+    run_mf<4>("MFMA x32 + 4 ds_read_b128 per iteration, ONLY wave 0 reads", 1);
+    run_mf<16>("MFMA x32 + 16 ds_read_b128 per iteration, ALL four waves read", 15);
+    run_mf<16>("MFMA x32 + 16 ds_read_b128 per iteration, ONLY wave 0 reads", 1);
     return 0;
 }

@@ -96,8 +96,14 @@ __device__ __forceinline__ f32x4 ld4(const char *p) { return *(const f32x4 *)p; 
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// 128-bit store for code that continues with INLINE-ASM vector instructions.  gfx950 hazard: a VALU write to the data VGPRs of a
+// store wider than 64 bits needs 2 wait states after the store; hipcc's hazard recogniser inserts them for instructions it can
+// see, but an `asm` statement is opaque to it -- a v_pk_add_f32 from asm that recycled the store's registers right behind it
+// corrupted lanes 12-15 of every row of 16 (the part of the data the store path reads last; round 3, found by bisecting two
+// epilogue re-orderings that only changed register allocation).  The s_nop is pinned behind the store by the memory clobber.
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    asm volatile("s_nop 1" ::: "memory");
 }
 // cache-policy variants (aux: bit 0 sc0, bit 1 nt, bit 4 sc1): weight fragments are read once per workgroup and never from
 // this CU's L1 again -- XQ_W_AUX selects how they pass through the caches
@@ -347,16 +353,19 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     };
 
     // ---- prologue ------------------------------------------------------------------------------------------
+    // the input of chunks 0 and 1 first (one HBM latency, not two; it is what the first MFMA waits for), then the weights, then
+    // the zero fill of the staging buffers while both are in flight
+    f32x4 x1[2];
+    load_x(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) x1[k] = buf_ld4(xrs, xgk[k], 32);
 #pragma unroll
     for (int f = 0; f < POOL; ++f) { if (f < NF) load_frag(0, f, f); else load_frag(1, f - NF, f); }
+    __builtin_amdgcn_sched_barrier(0);
     {
         f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int o = tid * 16; o < 2 * XRAW; o += 256 * 16) *(f32x4 *)(Xr + o) = z;
     }
-    f32x4 x1[2];
-    load_x(0);                                        // chunks 0 and 1 are fetched together: one HBM latency, not two
-#pragma unroll
-    for (int k = 0; k < 2; ++k) x1[k] = buf_ld4(xrs, xgk[k], 32);
     __syncthreads();                                  // zero fill before the first stores
     store_x(0);
 #pragma unroll
@@ -436,11 +445,16 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
         const float rlo = relu ? 0.0f : -__builtin_inff();
         constexpr int ESTR_R = 64 + XQ_EPAD_WIDE;
         auto goff = [&](int n, int it) __attribute__((always_inline)) { return (unsigned)(32 * n + ((it / 3) * 9 + it % 3) * Cs) * 4u; };
+#ifndef XQ_RES_SPREAD
+#define XQ_RES_SPREAD 2       // round 0's residual loads go out this many per column-transform segment (0: all twelve up front, -0.5 %: the issue of twelve back-to-back loads blocks the wave like stores do)
+#endif
         f32x4 resv[2][6], bv[4], pend[12];
+        if (!XQ_RES_SPREAD) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int it = 0; it < 6; ++it) resv[s][it] = buf_ld4(rrs, ooff, goff(s, it));
+                for (int it = 0; it < 6; ++it) resv[s][it] = buf_ld4(rrs, ooff, goff(s, it));
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) bv[n] = *(const f32x4 *)(bias + cog * NCO + 32 * n + co);
         float *E = (float *)lds;
@@ -469,6 +483,10 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
                     }
                     const int seg = s * 8 + e / 2;                               // 0 .. 15
                     if (rd == 1 && seg < 12) buf_st4(yrs, ooff, goff(seg / 6, seg % 6), pend[seg]);   // round 0's vector `seg`
+                    if (XQ_RES_SPREAD && rd == 0) {
+#pragma unroll
+                        for (int j = seg * XQ_RES_SPREAD; j < (seg + 1) * XQ_RES_SPREAD && j < 12; ++j) resv[j / 6][j % 6] = buf_ld4(rrs, ooff, goff(j / 6, j % 6));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -482,9 +500,9 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
                     const float *e0 = er + yb * TILES * ESTR_R + 32 * s;
                     const int pstride = 3 * TILES * ESTR_R;      // next Winograd row p
                     f32x4 y;
-                    if (ya == 0) y = *(const f32x4 *)(e0) + *(const f32x4 *)(e0 + pstride) + *(const f32x4 *)(e0 + 2 * pstride);
-                    else y = *(const f32x4 *)(e0 + pstride) - *(const f32x4 *)(e0 + 2 * pstride) - *(const f32x4 *)(e0 + 3 * pstride);
-                    y = y + bv[n] + resv[s][it];
+                    if (ya == 0) y = pk_add4(pk_add4(*(const f32x4 *)(e0), *(const f32x4 *)(e0 + pstride)), *(const f32x4 *)(e0 + 2 * pstride));
+                    else y = pk_sub4(pk_sub4(*(const f32x4 *)(e0 + pstride), *(const f32x4 *)(e0 + 2 * pstride)), *(const f32x4 *)(e0 + 3 * pstride));
+                    y = pk_add4(pk_add4(y, bv[n]), resv[s][it]);
                     y.x = max1(rlo, y.x); y.y = max1(rlo, y.y); y.z = max1(rlo, y.z); y.w = max1(rlo, y.w);
                     if (rd == 0) {
                         pend[s * 6 + it] = y;
