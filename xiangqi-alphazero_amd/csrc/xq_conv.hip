@@ -36,6 +36,12 @@
 // Epilogue: the column half of A^T M A in registers, the row half across the 4 waves through LDS (one 32-channel half
 // at a time over the staging buffers), then bias + residual + ReLU and NHWC stores.
 // Blocks are dealt so that each XCD works on one 64-channel slice of U at a time (1.3 MB at C=256: L2-resident).
+// The WIDE variant (NT = 4, one workgroup per CU, 128 output channels, 320 accumulators in VGPRs + AGPRs) differs in three
+// places, each explained where it happens: 16 weight-fragment registers (a fragment is fetched 64 MFMAs ahead), the input
+// loads of the prologue before everything else, and an epilogue pipelined against its own global stores.  Cost model used
+// throughout (measured, tests/microbench/valu_rates.hip): the fp32 MFMA runs on the vector ALU's multipliers, so every
+// vector instruction beside it costs its ~5 issue cycles; an LDS read ~6; a store or load issued into a full queue blocks
+// the wave (~260 / ~130 cycles each when all CUs do it), a spaced one costs its slot.
 #include <type_traits>
 
 #include "xq_common.h"
@@ -115,6 +121,7 @@ __device__ __forceinline__ f32x4 buf_ld4_w(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 __device__ __forceinline__ void st4_y(float *p, f32x4 v) {
     if (XQ_ABL & 16384) __builtin_nontemporal_store(v, (f32x4 *)p); else *(f32x4 *)p = v;
+    asm volatile("s_nop 1" ::: "memory");          // store-data hazard against the inline-asm VALU that follows (see buf_st4)
 }
 __device__ __forceinline__ f32x4 ld4_r(const float *p) {
     if (XQ_ABL & 32768) return __builtin_nontemporal_load((const f32x4 *)p);
