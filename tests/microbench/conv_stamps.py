@@ -1,4 +1,6 @@
-"""Per-workgroup timeline of k_wino_conv<4> from a diagnostic build (-DXQ_STAMP=1; not a test):
+"""Per-workgroup timeline of k_wino_conv<4> from a diagnostic build (-DXQ_STAMP=1; not a test).  The stamp code lives in the kernel
+source of commit bbf12af (git show bbf12af:xiangqi-alphazero_amd/csrc/xq_conv.hip), not in the shipped kernel:
+    tests/microbench/build_ref.sh does not pass defines -- build that revision by hand with -DXQ_STAMP=1, then
     python tests/microbench/conv_stamps.py tests/microbench/lab/libxq_stamp.so [--b 8192] [--c 256]
 For each case (residual yes/no, XQ_CONV_STAGGER off / on) it launches the kernel a few times, reads the stamps of the last
 launch (100 MHz wall clock: kernel entry, end of main loop, last store issued, stores completed) and prints how long a

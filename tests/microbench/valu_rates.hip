@@ -151,6 +151,48 @@ __global__ __launch_bounds__(256, 1) void kmf(unsigned long long *out, float *si
     if (s == 1234.5f) sink[tid] = s;
     if (lane == 0) out[blockIdx.x * 4 + wave] = (t1 - t0) / iters;
 }
+// the same MFMA stream with V buffer_load_dwordx4 per iteration from an L2-resident region (results consumed one iteration later)
+template <int V>
+__global__ __launch_bounds__(256, 1) void kmv(unsigned long long *out, float *sink, const float *g, int iters) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = tid * 0.001f, b = 1.0f + lane * 0.01f;
+    f32x4 u[V > 0 ? V : 1];
+    for (int i = 0; i < (V > 0 ? V : 1); ++i) u[i] = f32x4{a, b, a, b};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 1 << 22, 0x00020000);
+    const unsigned voff = (blockIdx.x % 8) * 262144 + wave * 16384 + lane * 16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(V > 0 ? u[i % (V > 0 ? V : 1)].x : a, b, acc[i & 7], 0, 0, 0);
+            if (V > 0 && (i % (32 / (V > 0 ? V : 1))) == (32 / (V > 0 ? V : 1)) - 1)
+                u[i / (32 / V)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((it * V + i / (32 / V)) & 15) * 1024, 0));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][5];
+    if (s == 1234.5f) sink[tid] = s;
+    if (lane == 0) out[blockIdx.x * 4 + wave] = (t1 - t0) / iters;
+}
+template <int V>
+static void run_mv(const char *name) {
+    unsigned long long *d;
+    float *sink, *g;
+    hipMalloc(&d, 256 * 4 * 8);
+    hipMalloc(&sink, 4096);
+    hipMalloc(&g, 1 << 22);
+    hipLaunchKernelGGL(kmv<V>, dim3(256), dim3(256), 0, 0, d, sink, g, 200);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(1024);
+    hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    printf("%-70s median %6llu  cycles per 32 MFMAs (2048 = MFMA only)\n", name, h[512]);
+    hipFree(d); hipFree(sink); hipFree(g);
+}
+
 template <int R>
 static void run_mf(const char *name, int readers) {
     unsigned long long *d;
@@ -209,6 +251,10 @@ int main() {
     run<11>("store dwordx4, 8 lanes per line, 1 CU in 32 active", 4, 32);
     run<13>("load  dwordx4, 8 lanes per line, 1 CU in 8 active", 4, 8);
     run<6>("ds_write_b128 lane-linear, 1 CU in 8 active", 8, 8);
+    run_mv<0>("MFMA x32 per iteration, no loads");
+    run_mv<4>("MFMA x32 + 4 buffer_load_dwordx4 (L2-resident) per iteration");
+    run_mv<8>("MFMA x32 + 8 buffer_load_dwordx4 (L2-resident) per iteration");
+    run_mv<16>("MFMA x32 + 16 buffer_load_dwordx4 (L2-resident) per iteration");
     run_mf<0>("MFMA x32 per iteration, no LDS reads", 0);
     run_mf<8>("MFMA x32 + 8 ds_read_b128 per iteration, ALL four waves read", 15);
     run_mf<8>("MFMA x32 + 8 ds_read_b128 per iteration, ONLY wave 0 reads", 1);
