@@ -22,8 +22,8 @@ rank runs its own 8192 games; no collective in the data path.  The same line als
   * "games_per_hour_measured": COMPLETE games under the reference's termination rules at BASELINE configs[1]
     (1024 games, 400 sims/move, 128x6) played inside this run, unless --complete-games 0;
   * "cpu_baseline" (N = 1, rank 0): the reference's mode-1 worker restated on the host cores;
-  * "throughput_mode" (only with --throughput-mode): a labelled REDUCED-PRECISION second measurement (bf16, ROCm library
-    convolutions) -- never the headline, outside the 1e-5 contract.
+  * "throughput_mode" (only with --throughput-mode): a labelled REDUCED-PRECISION second measurement (the hand-written bf16
+    convolution, hip_net.HipBf16Evaluator) -- never the headline, outside the 1e-5 contract.
 """
 import argparse
 import json
@@ -68,9 +68,9 @@ def parse_args():
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--evaluator", default="hip", choices=["hip", "torch", "nhwc", "bf16"])
+    ap.add_argument("--evaluator", default="hip", choices=["hip", "torch", "nhwc", "bf16", "bf16-lib"])
     ap.add_argument("--throughput-mode", action="store_true",
-                    help="add a second, labelled measurement with the reduced-precision (bf16, ROCm library) evaluator")
+                    help="add a second, labelled measurement with the reduced-precision evaluator (hand-written bf16 convolution)")
     ap.add_argument("--peaked", action="store_true", help="headline measurement itself on peaked-policy weights")
     ap.add_argument("--no-peaked", action="store_true", help="skip the second (peaked) measurement")
     ap.add_argument("--complete-games", type=int, default=1024,
@@ -509,8 +509,10 @@ def main():
                                               "expand_backup": round(mp["exp_ms"], 3)},
                              "tree": ptree, "tree_roofline": ptree_roof}
         if mt is not None:
-            out["throughput_mode"] = {"label": "REDUCED PRECISION, not the headline and outside the 1e-5 contract: bf16 weights/activations on the "
-                                               "ROCm library's bf16 MFMA convolutions (evaluator.Bf16ThroughputEvaluator)",
+            out["throughput_mode"] = {"label": "REDUCED PRECISION, not the headline and outside the 1e-5 contract: the residual tower on the "
+                                               "hand-written bf16 Winograd convolution (hip_net.HipBf16Evaluator: transformed inputs and filters "
+                                               "rounded to bf16, float32 accumulation, float32 activations in HBM, float32 stem and heads)",
+                                      "roofline": mt["roof"],
                                       "dtype": "bf16", "value": round(mt_sims / mt_el, 1), "unit": "simulations/s",
                                       "ms_per_step": round(1e3 * mt_el / args.steps, 3), "evaluator": mt["ev_name"],
                                       "breakdown_ms": {"select": round(mt["sel_ms"], 3), "evaluate": round(mt["nn_ms"], 3),

@@ -269,6 +269,17 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
  * float32[C/128][C/8][20][2][128][4] (the same element formula with 128-channel blocks), channels in {128, 256, 512}. */
 #define XQ_CONV_WIDE 4
 
+/* REDUCED-PRECISION throughput mode of the same convolution (never the parity path; outside the 1e-5 contract): the identical
+ * fused Winograd decomposition with the 20 per-frequency products on the bf16 MFMA (operands rounded to bf16 after the float32
+ * transforms, float32 accumulation, float32 activations in HBM).  Replaces nothing in the reference -- its own inference is
+ * float32 (model.py:109-124); it is the "throughput mode" of SURVEY.md section 7.
+ *   dev_u_bf16 : bf16[C/128][C/16][20][2][128][8], u[cog][chunk][5p+j][h][co][k] = the float32 tensor's element for output
+ *                channel 128*cog+co and input channel 16*chunk+8*h+k, rounded to nearest-even;  xq_wino_weight_bytes_bf16(C) = 40 C^2.
+ *   channels in {128, 256, 512}; flags: XQ_CONV_RELU, XQ_CONV_REVERSE. */
+size_t xq_wino_weight_bytes_bf16(int channels);
+int xq_wino_conv3x3_bf16(const float *dev_x, const void *dev_u_bf16, const float *dev_bias, const float *dev_residual,
+                         float *dev_y, int batch, int channels, int flags, void *stream);
+
 /* =====================================================================================
  * Next row (section 8f.1) -- training-batch materialisation.  Replaces SelfPlayDataset.__getitem__ + augment_data
  * (training/train.py:114-151) and _augment_data (training/parallel_selfplay.py:137-151) for a batch drawn from a

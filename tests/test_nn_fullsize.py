@@ -470,24 +470,86 @@ def test_evaluate_legal_matches_dense_logits_on_engine_requests():
     assert eng.stats()["overflow"] == 0
 
 
-def test_bf16_throughput_mode_is_labelled_and_outside_the_contract():
-    """The reduced-precision evaluator (bench.py --throughput-mode) on the golden positions: it tracks the reference
-    loosely (value within 3e-2, top-1 policy move mostly the same) and -- stated here so nobody mistakes it for the parity
-    path -- MISSES the 1e-5 contract by orders of magnitude."""
+@pytest.mark.parametrize("kind", ["bf16", "bf16-lib"])
+def test_bf16_throughput_mode_is_labelled_and_outside_the_contract(kind):
+    """The reduced-precision evaluators (bench.py --throughput-mode = 'bf16', the hand-written bf16 convolution; 'bf16-lib' the
+    ROCm-library comparison) on the golden positions: they track the reference loosely (value within 3e-2) and -- stated here so
+    nobody mistakes them for the parity path -- MISS the 1e-5 contract by orders of magnitude."""
     import torch
     from xiangqi_alphazero_amd import evaluator, model, weights
     g = G.nn_golden()
     states = torch.from_numpy(_golden_states(g)).cuda()
     net = model.XiangqiNet(128, 6)
     net.load_state_dict(weights.make_state_dict(128, 6))
-    ev, name = evaluator.make_evaluator(net, "cuda", "bf16")
-    assert "bf16" in name and "throughput" in name
-    logits, v = ev(states)
+    ev, name = evaluator.make_evaluator(net, "cuda", kind)
+    assert "bf16" in name and "throughput" in name and ("hip" in name) == (kind == "bf16")
+    logits, v = ev(states, full_policy=True) if kind == "bf16" else ev(states)
     assert logits.dtype == torch.float32 and logits.shape == (len(states), 8100)
     err_v = np.abs(v.cpu().numpy() - g["128x6_value"]).max()
     assert 1e-5 < err_v < 3e-2, err_v
+    # probabilities: these golden weights give a near-uniform policy (top probability ~1e-3), so the absolute error can sit
+    # under 1e-5 while the RELATIVE error is 1e-3..1e-2 -- three to four decades above the float32 path's
     probs = torch.softmax(logits, 1).cpu().numpy()
-    assert np.abs(np.take_along_axis(probs, g["128x6_top_idx"], axis=1) - g["128x6_top_prob"]).max() > 1e-5
+    top = np.take_along_axis(probs, g["128x6_top_idx"], axis=1)
+    assert 1e-4 < (np.abs(top - g["128x6_top_prob"]) / g["128x6_top_prob"]).max() < 0.2
+
+
+@pytest.mark.parametrize("channels,batch", [(128, 67), (256, 515), (512, 33)])
+def test_bf16_conv_tracks_the_fp32_conv(channels, batch):
+    """xq_wino_conv3x3_bf16 against xq_wino_conv3x3 on the same input, filters, bias and skip (ragged batches: the last tile
+    group is partial): same result up to bf16 rounding of the transformed operands -- rms error below 3 % of the output's rms,
+    and ABOVE 1e-5 (it is a different arithmetic, labelled as such); front-to-back and back-to-front launches agree bit for bit;
+    rows past the batch are not written."""
+    import torch
+    from xiangqi_alphazero_amd import hip
+    gen = torch.Generator().manual_seed(channels + batch)
+    w = (torch.randn(channels, channels, 3, 3, generator=gen) * (2.0 / (9 * channels)) ** 0.5).cuda()
+    x = torch.randn(batch, 90, channels, generator=gen).relu().cuda()
+    res = torch.randn(batch, 90, channels, generator=gen).cuda()
+    bias = (torch.randn(channels, generator=gen) * 0.1).cuda()
+    u32, u16 = hip.wino_transform_weights(w, 128), hip.wino_transform_weights_bf16(w)
+    assert u16.dtype == torch.bfloat16 and u16.numel() == u32.numel()
+    for residual in (None, res):
+        for relu in (True, False):
+            ref = hip.wino_conv3x3(x, u32, bias, torch.empty_like(x), residual, relu)
+            pad = torch.full((batch + 3, 90, channels), 7.0, device="cuda")
+            out = hip.wino_conv3x3_bf16(x, u16, bias, pad[:batch], residual, relu)
+            back = hip.wino_conv3x3_bf16(x, u16, bias, torch.empty_like(x), residual, relu, reverse=True)
+            assert torch.equal(out, back)
+            assert bool((pad[batch:] == 7.0).all())
+            assert bool(torch.isfinite(out).all())
+            rel = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            assert 1e-5 < rel < 3e-2, (channels, residual is not None, relu, rel)
+
+
+def test_bf16_evaluator_runs_the_engine_protocol():
+    """The throughput-mode evaluator serves the engine's sparse hand-off (legal-move logits + value) like the float32 one: same
+    shapes, values close to the float32 evaluator's on the same leaf batch (loose: reduced precision), graph capture works."""
+    import torch
+    from xiangqi_alphazero_amd import engine, evaluator, model, weights
+    net = model.XiangqiNet(128, 2)
+    net.load_state_dict(weights.make_state_dict(128, 2))
+    e32, _ = evaluator.make_evaluator(net, "cuda", "hip")
+    e16, _ = evaluator.make_evaluator(net, "cuda", "bf16")
+    eng = engine.SelfPlayEngine(engine.make_config(96, 16, random_opening_moves=4, seed=3), "cuda", evaluator=e32)
+    for _ in range(6):
+        eng.step()
+    x = eng.select()
+    counts = eng.req_counts.clone()
+    l32, v32 = e32.evaluate_legal(x, eng.req_moves, eng.req_counts)
+    l32, v32 = l32.clone(), v32.clone()
+    l16, v16 = e16.evaluate_legal(x, eng.req_moves, eng.req_counts)
+    live = torch.arange(128, device="cuda")[None, :] < counts[:, None]
+    assert (v16 - v32).abs().max().item() < 3e-2
+    assert 1e-6 < ((l16 - l32).abs() * live).max().item() < 0.05 * max(1.0, (l32.abs() * live).max().item())
+    eng.expand_legal(l16, v16)
+    eng.evaluator = e16
+    eng.capture_step(warmup=1)
+    assert eng.launch_mode == "graph", eng.capture_error
+    before = eng.stats()["sims"]
+    for _ in range(5):
+        eng.step()
+    assert eng.stats()["sims"] > before and eng.stats()["overflow"] == 0
 
 
 def test_evaluator_update_refreshes_weights_in_place():

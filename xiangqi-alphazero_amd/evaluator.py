@@ -55,7 +55,10 @@ def make_evaluator(net: XiangqiNet, device, kind: str = "hip"):
     """-> (callable evaluator for the engine, name).
     'hip' (the product path; 'auto' is an alias): the hand-written kernels (csrc/xq_conv.hip, xq_nn.hip); raises
     `hip.XqError` when the library or a kernel is missing -- it never changes backend behind the caller's back.
-    'nhwc' / 'torch': ROCm-library evaluators (MIOpen / hipBLASLt), kept for comparison numbers only; selected explicitly."""
+    'bf16': REDUCED-PRECISION throughput mode on the hand-written bf16 convolution (hip_net.HipBf16Evaluator); outside the
+    1e-5 contract, selected explicitly only.
+    'nhwc' / 'torch' / 'bf16-lib': ROCm-library evaluators (MIOpen / hipBLASLt), kept for comparison numbers only; selected
+    explicitly."""
     if kind in ("auto", "hip"):
         from .hip_net import HipResNetEvaluator
         return HipResNetEvaluator(net, device, engine_policy=True), "hip-winograd-mfma-f32"
@@ -64,13 +67,16 @@ def make_evaluator(net: XiangqiNet, device, kind: str = "hip"):
     if kind == "torch":
         return BatchedEvaluator(net, device), "torch-rocm-f32"
     if kind == "bf16":
+        from .hip_net import HipBf16Evaluator
+        return HipBf16Evaluator(net, device, engine_policy=True), "hip-winograd-mfma-bf16-throughput-mode"
+    if kind == "bf16-lib":
         return Bf16ThroughputEvaluator(net, device), "rocm-library-bf16-throughput-mode"
     raise ValueError("unknown evaluator kind %r" % (kind,))
 
 
 class Bf16ThroughputEvaluator:
-    """REDUCED-PRECISION throughput mode (hard parts: "keep an fp32 parity mode and a bf16 throughput
-    mode, report both"): the same folded network with bf16 weights and activations on the ROCm library's bf16 MFMA
+    """LIBRARY comparison for the reduced-precision mode (kind 'bf16-lib'; the throughput mode proper is the hand-written
+    hip_net.HipBf16Evaluator): the same folded network with bf16 weights and activations on the ROCm library's bf16 MFMA
     convolutions (channels-last), fp32 accumulation inside the library kernels, fp32 heads' outputs.  It does NOT meet the
     1e-5 contract (bf16 carries 8 significand bits; tests/test_nn_fullsize.py states the measured deviation) and is never
     the headline: bench.py reports it as a second, labelled object.  Library kernels only -- comparison material, not

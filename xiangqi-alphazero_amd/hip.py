@@ -102,6 +102,9 @@ def lib():
     L.xq_wino_weight_bytes.argtypes = [i32]
     L.xq_wino_weight_bytes.restype = C.c_size_t
     L.xq_wino_conv3x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.xq_wino_weight_bytes_bf16.argtypes = [i32]
+    L.xq_wino_weight_bytes_bf16.restype = C.c_size_t
+    L.xq_wino_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.xq_policy_head_legal.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.xq_value_head.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.xq_engine_requests.argtypes = [C.POINTER(Engine), C.POINTER(vp), C.POINTER(vp)]
@@ -115,7 +118,8 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_engine_workspace_bytes", "xq_engine_init", "xq_engine_select", "xq_engine_expand",
            "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
            "xq_bias_act", "xq_stem_conv", "xq_heads_1x1", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch",
-           "xq_policy_head_legal", "xq_value_head", "xq_engine_requests", "xq_engine_expand_legal", "xq_engine_drain_device"]
+           "xq_policy_head_legal", "xq_value_head", "xq_engine_requests", "xq_engine_expand_legal", "xq_engine_drain_device",
+           "xq_wino_weight_bytes_bf16", "xq_wino_conv3x3_bf16"]
 
 
 def check(rc: int, what: str):
@@ -270,6 +274,33 @@ def wino_transform_weights(w: torch.Tensor, co_block: int = 64) -> torch.Tensor:
     u = u.reshape(20, c // co_block, co_block, c // 8, 2, 4)                               # xi, cog, co, chunk, quad, k
     u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, k
     return u.to(w.device)
+
+
+def wino_transform_weights_bf16(w: torch.Tensor) -> torch.Tensor:
+    """Folded 3x3 filters float32[C,C,3,3] -> the bf16 layout of xq_wino_conv3x3_bf16 (REDUCED PRECISION, throughput mode):
+    the float32 wide-layout tensor of `wino_transform_weights(w, 128)` regrouped to 16-channel chunks and rounded to bf16,
+    bf16[C/128][C/16][20][2][128][8] with input channel 16*chunk + 8*h + k."""
+    c = w.shape[0]
+    if c % 128 or (c // 16) % 4:
+        raise XqError("wino_transform_weights_bf16: C must be 128, 256 or 512")
+    u = wino_transform_weights(w, 128)                                 # [cog, chunk8, xi, quad, co, k4]
+    ng = c // 128
+    u = u.view(ng, c // 16, 2, 20, 2, 128, 4)                          # cog, chunk16, h, xi, quad, co, k4
+    u = u.permute(0, 1, 3, 2, 5, 4, 6).contiguous().view(ng, c // 16, 20, 2, 128, 8)   # cog, chunk16, xi, h, co, (quad, k4)
+    return u.to(torch.bfloat16).contiguous()
+
+
+def wino_conv3x3_bf16(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, residual=None,
+                      relu: bool = True, reverse: bool = False) -> torch.Tensor:
+    """REDUCED-PRECISION convolution (xq_wino_conv3x3_bf16): x, out, residual float32[B, 90, C]; u from
+    `wino_transform_weights_bf16`."""
+    b, n, c = x.shape
+    if n != 90 or not x.is_contiguous() or not out.is_contiguous() or out.shape != x.shape or u.dtype != torch.bfloat16:
+        raise XqError("wino_conv3x3_bf16: float32[B,90,C] contiguous tensors and bf16 weights required")
+    check(lib().xq_wino_conv3x3_bf16(x.data_ptr(), u.data_ptr(), bias.data_ptr(),
+                                     None if residual is None else residual.data_ptr(), out.data_ptr(), b, c,
+                                     int(relu) | (2 if reverse else 0), stream_ptr(x.device)), "xq_wino_conv3x3_bf16")
+    return out
 
 
 def wino_conv3x3(x: torch.Tensor, u: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, residual=None,
