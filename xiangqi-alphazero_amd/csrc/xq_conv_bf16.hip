@@ -113,10 +113,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv_bf16(const float *__restri
 
     f32x16 acc[5][NT];
     f32x4 xreg[4];
-    bf16x8 a[5], ub[POOL];
+    bf16x8 a[2][5], ub[POOL];                        // a[k & 1]: the transformed input of chunk k (double-buffered: chunk c + 1 is
+                                                     // transformed while chunk c multiplies)
     auto load_x = [&](int chunk) __attribute__((always_inline)) {
+        const unsigned kill = chunk < NCH ? 0u : 0xFFFFFFF0u;          // past the last chunk: out-of-range offsets, no memory traffic
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xreg[k] = buf_ld4(xrs, xgk[k], chunk * 64);
+        for (int k = 0; k < 4; ++k) xreg[k] = buf_ld4(xrs, xgk[k] | kill, chunk * 64);
     };
     auto store_x = [&](int chunk) __attribute__((always_inline)) {
         char *dst = Xr + (chunk & 1) * XRAW;
@@ -127,9 +129,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv_bf16(const float *__restri
         const int q = (f / NT) == 0 ? 1 : (f / NT) == 1 ? 2 : (f / NT) == 2 ? 3 : (f / NT) == 3 ? 0 : 4;
         ub[slot] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, ul, (unsigned)chunk * UCHUNK_BYTES + q * (2 * NCO * 16) + (f % NT) * (32 * 16), 0));
     };
-    // the five transformed vectors of one 4-channel half (float32; formulas of xq_conv.hip)
-    auto transform_half = [&](const char *base, f32x4 (&v)[5]) __attribute__((always_inline)) {
-        f32x4 w[5];
+    // one 4-channel half of a lane's 8 channels: float32 transform (formulas of xq_conv.hip), rounded to bf16 into elements
+    // 4 half .. 4 half + 3 of the five A operands
+    auto transform_half = [&](const char *base, bf16x8 (&dst)[5], auto half_tag) __attribute__((always_inline)) {
+        constexpr int H4 = 4 * decltype(half_tag)::value;
+        f32x4 w[5], v[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) w[c] = ld4(base + tb1 + c * XSTRIDE) + sg * ld4(base + tb2 + c * XSTRIDE);
         const f32x4 t = w[3] - w[1];
@@ -138,18 +142,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv_bf16(const float *__restri
         v[2] = 3.0f * w[2] - (2.0f * w[1] + w[3]);
         v[3] = t;
         v[4] = (w[4] - w[2]) - 2.0f * t;
-    };
-    auto transform = [&](int buf) __attribute__((always_inline)) {
-        f32x4 lo[5], hi[5];
-        transform_half(Xr + buf * XRAW, lo);
-        transform_half(Xr + buf * XRAW + XPLANE, hi);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) a[q] = to_bf16(lo[q], hi[q]);
+        for (int q = 0; q < 5; ++q) {
+            dst[q][H4 + 0] = (__bf16)v[q].x; dst[q][H4 + 1] = (__bf16)v[q].y; dst[q][H4 + 2] = (__bf16)v[q].z; dst[q][H4 + 3] = (__bf16)v[q].w;
+        }
     };
-    // one chunk: 20 MFMAs; fragment 16 positions further down the stream replaces the one just used
+    // one chunk: 20 MFMAs of chunk c (fragment 16 positions further down the stream replaces the one just used), the transform of
+    // chunk c + 1 in two halves between them (the bf16 MFMA runs on the matrix core: the vector instructions fill its shadow)
     auto chunk_mfma = [&](int nchunk_u, int lchunk, auto first_tag, auto ph_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int PH = decltype(ph_tag)::value;
+        constexpr int P = PH & 1;
+        const char *nxt = Xr + (P ^ 1) * XRAW;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const int g = f / NT, nt = f % NT;
@@ -157,14 +161,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv_bf16(const float *__restri
             const int slot = (NF * PH + f) % POOL;
             if (FIRST) {
                 const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], ub[slot], zero, 0, 0, 0);
+                acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][q], ub[slot], zero, 0, 0, 0);
             } else if (nt == 3) {
                 // 20 accumulator tiles do not fit the 256 AGPRs: N-tile 3 is pinned to VGPRs (as in xq_conv.hip)
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[q]), "v"(ub[slot]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[P][q]), "v"(ub[slot]));
             } else {
-                acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], ub[slot], acc[q][nt], 0, 0, 0);
+                acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][q], ub[slot], acc[q][nt], 0, 0, 0);
             }
             if (!(XQ_BABL & 1)) { if (f + POOL < NF) load_frag(lchunk, f + POOL, slot); else load_frag(nchunk_u, f + POOL - NF, slot); }
+            if (!(XQ_BABL & 2)) {
+                if (f == 3) transform_half(nxt, a[P ^ 1], std::integral_constant<int, 0>{});
+                if (f == 11) transform_half(nxt + XPLANE, a[P ^ 1], std::integral_constant<int, 1>{});
+            }
         }
     };
 
@@ -185,16 +193,17 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv_bf16(const float *__restri
     for (int k = 0; k < 4; ++k) *(f32x4 *)(Xr + XRAW + xl[k]) = x1[k];
     load_x(2);
     __syncthreads();
-    transform(0);
+    transform_half(Xr, a[0], std::integral_constant<int, 0>{});
+    transform_half(Xr + XPLANE, a[0], std::integral_constant<int, 1>{});
     __syncthreads();
 
-    // ---- main loop: chunk c multiplies (a, fragments) of chunk c; then a <- transform of chunk c + 1 (buffer (c + 1) & 1), chunk c + 2 is
-    // stored into buffer c & 1 and chunk c + 3 fetched; one barrier per chunk
+    // ---- main loop, ONE barrier per chunk.  Step c: chunk c + 2 (fetched during step c - 1) is stored into buffer c & 1 -- last read by
+    // the transform of chunk c in step c - 1, before that step's barrier -- and chunk c + 3 fetched; chunk c multiplies while chunk
+    // c + 1 (buffer (c + 1) & 1, stored in step c - 1) is transformed.  Branch-free: past the end the loads are out of range, the
+    // stores and the transform work on dead buffers.
     auto step = [&](int c, auto first_tag, auto ph_tag) __attribute__((always_inline)) {
+        if (!(XQ_BABL & 4)) { store_x(c + 2); load_x(c + 3); }
         chunk_mfma(c + 1 < NCH ? c + 1 : c, c, first_tag, ph_tag);
-        if (c + 1 < NCH && !(XQ_BABL & 2)) transform((c + 1) & 1);
-        __syncthreads();                                  // every wave has read buffer (c + 1) & 1 ... and buffer c & 1 before that
-        if (c + 2 < NCH && !(XQ_BABL & 4)) { store_x(c + 2); if (c + 3 < NCH) load_x(c + 3); }
         __syncthreads();
     };
     step(0, std::true_type{}, std::integral_constant<int, 0>{});
