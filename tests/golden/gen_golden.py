@@ -18,7 +18,8 @@ Fixtures written (all small):
   game_traces.json      reference _play_one_game with every random draw injected (tests/draws.py)
   flip_perm.npy         8100-entry action permutation of _augment_data
   arena_traces.json     reference AlphaZeroTrainer._serial_evaluate with stub models: per-game winner/steps, totals
-  train_trace.json      reference AlphaZeroTrainer.train_network on a recorded game's augmented samples (fixed batch order)
+  train_trace.json      reference AlphaZeroTrainer.train_network on a recorded game's augmented samples (fixed batch order);
+                        train_trace_64x2.json: the same at 64x2 (the smallest net the hand-written convolution takes)
   nn_golden.npz         reference XiangqiNet outputs for generator weights (xiangqi-alphazero_amd/weights.py)
   nn_golden2.npz        the same for 256x20 and for peaked policies (policy_gain 8), plus the reference's priors over
                         the ordered legal moves (MCTS._mask_and_normalize of predict)
@@ -631,28 +632,30 @@ def gen_train():
         random.randint, random.choice, np.random.dirichlet, np.random.choice = saved
     aug = ref_sp._augment_data(data)
 
-    net = ref_model.XiangqiNet(num_channels=16, num_res_blocks=1)
-    net.load_state_dict(W.make_state_dict(16, 1, seed=3))
-    tc = types.SimpleNamespace(min_buffer_size=10, num_epochs=2, batch_size=20)
-    opt = torch.optim.Adam(net.parameters(), lr=0.002, weight_decay=1e-4)
-    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1, 80], gamma=0.1)
-    fake = types.SimpleNamespace(config=tc, replay_buffer=deque(aug, maxlen=50000), current_model=net, optimizer=opt,
-                                 scheduler=sch, device="cpu")
-    real_loader = ref_train.DataLoader
-    ref_train.DataLoader = lambda ds, **kw: real_loader(ds, **{**kw, "shuffle": False})
-    try:
-        stats = ref_train.AlphaZeroTrainer.train_network(fake)
-    finally:
-        ref_train.DataLoader = real_loader
-    sd = net.state_dict()
-    probe = {k: [float(x) for x in sd[k].flatten()[:8].double()] for k in
-             ("input_conv.0.weight", "res_blocks.0.conv2.weight", "policy_head.4.bias", "value_head.6.weight",
-              "input_conv.1.running_mean", "value_head.1.running_var")}
-    out = dict(game="maxlen", n_samples=len(aug), net=[16, 1], seed=3, num_epochs=2, batch_size=20, lr=0.002,
-               weight_decay=1e-4, milestones=[1, 80], gamma=0.1, stats={k: float(v) for k, v in stats.items()},
-               probe=probe, num_batches_tracked=int(sd["input_conv.1.num_batches_tracked"]))
-    json.dump(out, open(os.path.join(HERE, "train_trace.json"), "w"))
-    print("train", stats)
+    # 16x1: the original trace; 64x2: the smallest width the hand-written convolution takes (XiangqiNet.use_native_conv)
+    for (ch, nb, fname) in ((16, 1, "train_trace.json"), (64, 2, "train_trace_64x2.json")):
+        net = ref_model.XiangqiNet(num_channels=ch, num_res_blocks=nb)
+        net.load_state_dict(W.make_state_dict(ch, nb, seed=3))
+        tc = types.SimpleNamespace(min_buffer_size=10, num_epochs=2, batch_size=20)
+        opt = torch.optim.Adam(net.parameters(), lr=0.002, weight_decay=1e-4)
+        sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1, 80], gamma=0.1)
+        fake = types.SimpleNamespace(config=tc, replay_buffer=deque(aug, maxlen=50000), current_model=net, optimizer=opt,
+                                     scheduler=sch, device="cpu")
+        real_loader = ref_train.DataLoader
+        ref_train.DataLoader = lambda ds, **kw: real_loader(ds, **{**kw, "shuffle": False})
+        try:
+            stats = ref_train.AlphaZeroTrainer.train_network(fake)
+        finally:
+            ref_train.DataLoader = real_loader
+        sd = net.state_dict()
+        probe = {k: [float(x) for x in sd[k].flatten()[:8].double()] for k in
+                 ("input_conv.0.weight", "res_blocks.0.conv2.weight", "policy_head.4.bias", "value_head.6.weight",
+                  "input_conv.1.running_mean", "value_head.1.running_var")}
+        out = dict(game="maxlen", n_samples=len(aug), net=[ch, nb], seed=3, num_epochs=2, batch_size=20, lr=0.002,
+                   weight_decay=1e-4, milestones=[1, 80], gamma=0.1, stats={k: float(v) for k, v in stats.items()},
+                   probe=probe, num_batches_tracked=int(sd["input_conv.1.num_batches_tracked"]))
+        json.dump(out, open(os.path.join(HERE, fname), "w"))
+        print("train", fname, stats)
 
 
 if __name__ == "__main__":

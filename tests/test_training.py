@@ -11,8 +11,8 @@ from test_host_logic import _oracle_game_as_compact
 REF = "/root/reference/training"
 
 
-def _trace():
-    return json.load(open(os.path.join(G.GOLDEN, "train_trace.json")))
+def _trace(name="train_trace.json"):
+    return json.load(open(os.path.join(G.GOLDEN, name)))
 
 
 @pytest.mark.gpu
@@ -51,14 +51,99 @@ def test_replay_buffer_is_fifo_like_the_reference_deque():
 
 
 @pytest.mark.gpu
-def test_train_network_matches_reference_trace():
-    """Same data, weights, optimiser and batch order as the reference's train_network run recorded in the fixture:
+@pytest.mark.parametrize("channels,co_block", [(64, 64), (128, 64), (128, 128), (256, 128), (512, 64)])
+def test_device_filter_transform_equals_the_host_transform(channels, co_block):
+    """xq_wino_transform_filters (one launch on the device, what the train step uses every optimizer step) against the host's
+    float64 einsum (hip.wino_transform_weights, what self-play uses once per weight update): the same float32 values; the
+    data-gradient form equals the host transform of the transposed, 180-degree-rotated filters."""
+    import torch
+    from xiangqi_alphazero_amd import hip
+    w = (torch.randn(channels, channels, 3, 3, generator=torch.Generator().manual_seed(channels + co_block)) * 0.05).cuda()
+    for dgrad in (False, True):
+        host = hip.wino_transform_weights(w.flip(2, 3).transpose(0, 1).contiguous() if dgrad else w, co_block)
+        dev = hip.wino_transform_filters_device(w, co_block, dgrad)
+        assert dev.shape == host.shape
+        # float64 sums of three products taken in a different order may round differently in the last float32 bit
+        assert (dev - host).abs().max().item() <= 1.2e-7 * host.abs().max().item()
+        assert (dev != host).double().mean().item() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,batch", [(64, 5), (128, 37), (256, 256)])
+def test_native_conv_forward_and_gradients_equal_torch(channels, batch):
+    """native_conv.WinoConv3x3 (forward and data gradient on the hand-written kernel) against torch's convolution in float64 on the
+    same operands: output, dL/dx and dL/dw within 1e-5 of the largest magnitude (float32 Winograd rounding)."""
+    import torch
+    import torch.nn.functional as F
+    from xiangqi_alphazero_amd import native_conv
+    gen = torch.Generator().manual_seed(batch)
+    x = torch.randn(batch, channels, 10, 9, generator=gen).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(channels, channels, 3, 3, generator=gen) * (2.0 / (9 * channels)) ** 0.5).cuda().requires_grad_(True)
+    gy = torch.randn(batch, channels, 10, 9, generator=gen).cuda()
+    y = native_conv.conv3x3(x, w)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, padding=1)
+    y64.backward(gy.double())
+    for got, want in ((y, y64), (x.grad, x64.grad), (w.grad, w64.grad)):
+        assert (got.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    x2 = x.detach().contiguous().requires_grad_(True)                        # NCHW-contiguous input: same values (one copy inside)
+    assert torch.equal(native_conv.conv3x3(x2, w), y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,batch,with_res,relu", [(64, 3, False, True), (128, 20, True, True), (256, 256, True, True),
+                                                          (256, 64, False, False), (512, 7, True, False)])
+def test_fused_batchnorm_train_equals_torch_float64(channels, batch, with_res, relu):
+    """native_conv.BnAct (training-mode BatchNorm2d + skip-add + ReLU, hand-written) against torch in float64 on the same operands:
+    output, running statistics, and the gradients of x, the skip input, gamma and beta."""
+    import torch
+    import torch.nn.functional as F
+    from xiangqi_alphazero_amd import native_conv
+    gen = torch.Generator().manual_seed(channels + batch)
+    mk = lambda *shape: torch.randn(*shape, generator=gen)
+    x = (mk(batch, channels, 10, 9) * 1.7 + 0.3).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = mk(batch, channels, 10, 9).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+    bn = torch.nn.BatchNorm2d(channels).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(mk(channels).abs() + 0.5); bn.bias.copy_(mk(channels) * 0.2)
+        bn.running_mean.copy_(mk(channels) * 0.1); bn.running_var.copy_(mk(channels).abs() + 0.5)
+    rm0, rv0 = bn.running_mean.double().clone(), bn.running_var.double().clone()
+    gy = mk(batch, channels, 10, 9).cuda()
+    assert native_conv.bn_supported(bn)
+    y = native_conv.bn_act(x, bn, r, relu)
+    y.backward(gy)
+    assert int(bn.num_batches_tracked) == 1
+    x64 = x.detach().double().requires_grad_(True)
+    r64 = r.detach().double().requires_grad_(True) if with_res else None
+    g64, b64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    y64 = F.batch_norm(x64, rm0, rv0, g64, b64, True, bn.momentum, bn.eps)
+    if with_res:
+        y64 = y64 + r64
+    if relu:
+        y64 = F.relu(y64)
+    y64.backward(gy.double())
+    pairs = [(y, y64), (x.grad, x64.grad), (bn.weight.grad, g64.grad), (bn.bias.grad, b64.grad), (bn.running_mean, rm0), (bn.running_var, rv0)]
+    if with_res:
+        pairs.append((r.grad, r64.grad))
+    for i, (got, want) in enumerate(pairs):
+        assert (got.double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()), i
+    bn.eval()
+    assert not native_conv.bn_supported(bn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trace,native", [("train_trace.json", False), ("train_trace_64x2.json", False), ("train_trace_64x2.json", True)])
+def test_train_network_matches_reference_trace(trace, native):
+    """Same data, weights, optimiser and batch order as the reference's train_network run recorded in the fixture -- with the
+    tower's convolutions on the ROCm library and (native) on the hand-written Winograd kernel (XiangqiNet.use_native_conv):
     losses within 1e-4 relative; probed weights within 1e-4 absolute -- they move by up to 1.2e-2 in the six Adam steps
     (lr 2e-3) and Adam's normalised update amplifies last-bit gradient differences between GPU and CPU kernels."""
     import types
     import torch
     from xiangqi_alphazero_amd import model, training, weights
-    t = _trace()
+    t = _trace(trace)
     game = [x for x in G.game_traces() if x["name"] == t["game"]][0]
     arr, _ = _oracle_game_as_compact(game)
     buf = training.ReplayBuffer(50000)
@@ -67,17 +152,53 @@ def test_train_network_matches_reference_trace():
     net = model.XiangqiNet(*t["net"])
     net.load_state_dict(weights.make_state_dict(*t["net"], seed=t["seed"]))
     net = net.cuda()
+    if native:
+        net.use_native_conv(True)
     opt = torch.optim.Adam(net.parameters(), lr=t["lr"], weight_decay=t["weight_decay"])
     sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=t["milestones"], gamma=t["gamma"])
     cfg = types.SimpleNamespace(min_buffer_size=10, num_epochs=t["num_epochs"], batch_size=t["batch_size"])
     stats = training.train_network(net, opt, sch, buf, cfg, shuffle=False)
+    # 64x2: six Adam steps amplify float32 rounding differences between GPU and CPU kernels further than at 16x1 -- the ROCm
+    # library path itself lands 3e-4 from the reference's CPU run; both paths are held to 1e-3 / 5e-4 there
+    rtol, atol = (1e-4, 1e-4) if t["net"][0] == 16 else (1e-3, 5e-4)
     for k in ("policy_loss", "value_loss", "total_loss", "learning_rate"):
-        assert abs(stats[k] - t["stats"][k]) <= 1e-4 * abs(t["stats"][k]) + 1e-7, (k, stats[k], t["stats"][k])
+        assert abs(stats[k] - t["stats"][k]) <= rtol * abs(t["stats"][k]) + 1e-7, (k, stats[k], t["stats"][k])
     sd = net.state_dict()
     assert int(sd["input_conv.1.num_batches_tracked"]) == t["num_batches_tracked"]
     for k, want in t["probe"].items():
-        np.testing.assert_allclose(sd[k].flatten()[:8].double().cpu().numpy(), want, rtol=0, atol=1e-4, err_msg=k)
+        np.testing.assert_allclose(sd[k].flatten()[:8].double().cpu().numpy(), want, rtol=0, atol=atol, err_msg=k)
     assert training.train_network(net, opt, sch, training.ReplayBuffer(100), cfg) == {}     # below min_buffer_size
+
+
+@pytest.mark.gpu
+def test_native_conv_step_gradients_equal_the_library_step():
+    """One forward/backward of the whole training module (train mode, batch statistics) from the same weights and batch with
+    XiangqiNet.use_native_conv on and off: loss and EVERY parameter gradient agree to float32 rounding (1e-4 of the gradient's
+    largest entry) -- the hand-written forward and data-gradient convolutions change nothing else in the step."""
+    import copy
+    import torch
+    import torch.nn.functional as F
+    from xiangqi_alphazero_amd import model, weights
+    net = model.XiangqiNet(128, 3)
+    net.load_state_dict(weights.make_state_dict(128, 3, seed=9))
+    a = net.cuda().train()
+    b = copy.deepcopy(a).use_native_conv(True)
+    assert b.res_blocks[0].native_conv and not a.res_blocks[0].native_conv
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.rand(96, 15, 10, 9, generator=gen) < 0.1).float().cuda()
+    pi = torch.softmax(torch.randn(96, 8100, generator=gen), 1).cuda()
+    z = (torch.rand(96, 1, generator=gen) * 2 - 1).cuda()
+    losses = []
+    for m in (a, b):
+        logits, value = m(x)
+        loss = -torch.mean(torch.sum(pi * F.log_softmax(logits, dim=1), dim=1)) + F.mse_loss(value, z)
+        loss.backward()
+        losses.append(loss.item())
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0])
+    for (name, p), q in zip(a.named_parameters(), b.parameters()):
+        scale = p.grad.abs().max().item()
+        assert (p.grad - q.grad).abs().max().item() <= 1e-4 * scale + 1e-9, name
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
 
 
 def test_checkpoint_files_have_the_reference_layout(tmp_path):

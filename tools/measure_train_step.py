@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--cpu-batches", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--native-conv", type=int, default=1, help="1: tower convolutions (forward + data gradient) on the hand-written "
+                    "Winograd kernel (XiangqiNet.use_native_conv); 0: torch autograd on the ROCm library throughout")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -43,6 +45,7 @@ def main():
     net = model.XiangqiNet(a.channels, a.blocks)
     net.load_state_dict(weights.make_state_dict(a.channels, a.blocks))
     net = net.cuda()
+    net.use_native_conv(bool(a.native_conv))
     opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-4)
     sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[50, 80], gamma=0.1)
     tcfg = types.SimpleNamespace(min_buffer_size=1, num_epochs=1, batch_size=a.batch)
@@ -82,7 +85,10 @@ def main():
     print(json.dumps({
         "net": "%dx%d" % (a.channels, a.blocks), "batch": a.batch, "buffer_samples": len(buf), "epochs_timed": a.epochs,
         "gpu_samples_per_s": round(gpu_rate, 1), "gpu_ms_per_batch": round(1e3 * gpu_s / (a.epochs * -(-len(buf) // a.batch)), 2),
-        "gpu_path": "device-resident compact buffer + xq_samples_to_batch + torch autograd (fp32)",
+        "gpu_path": "device-resident compact buffer + xq_samples_to_batch + torch autograd (fp32); tower convolutions: "
+                    + ("forward and data gradient on xq_wino_conv3x3 (channels-last), weight gradient ROCm library" if a.native_conv
+                       else "ROCm library"),
+        "native_conv": bool(a.native_conv),
         "cpu_samples_per_s": round(done / cpu_s, 1), "cpu_threads": torch.get_num_threads(), "cpu_samples_timed": done,
         "cpu_path": "the reference's train step restated (train.py:398-419), dense tuples, torch CPU",
         "policy_loss": stats.get("policy_loss")}))

@@ -613,6 +613,47 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
     }
 }
 
+
+// Filter transform on the device (train step: the filters change every optimizer step).  One thread = one output channel x four input
+// channels: 20 float4 stores, coalesced over the output channel.  float64 arithmetic as the host transform (hip.wino_transform_weights),
+// rounded once to float32.  `dgrad`: the filters of the data-gradient convolution, w'[co][ci][r][s] = w[ci][co][2 - r][2 - s].
+__global__ __launch_bounds__(256) void k_wino_filter_transform(const float *__restrict__ W, float *__restrict__ U, int C, int nco, int dgrad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= C * (C / 4)) return;
+    const int co = t % C, cq = t / C;
+    const double gr[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const double gc[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6.0, -1.0 / 6.0, 1.0 / 6.0}, {1.0 / 6.0, 2.0 / 6.0, 4.0 / 6.0}, {0.0, 0.0, 1.0}};
+    float out[20][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ci = 4 * cq + k;
+        double g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                g[r][q] = dgrad ? (double)W[((size_t)ci * C + co) * 9 + (2 - r) * 3 + (2 - q)] : (double)W[((size_t)co * C + ci) * 9 + r * 3 + q];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double tr[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tr[q] = gr[p][0] * g[0][q] + gr[p][1] * g[1][q] + gr[p][2] * g[2][q];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const double v = tr[0] * gc[j][0] + tr[1] * gc[j][1] + tr[2] * gc[j][2];
+                out[5 * p + j][k] = (float)(p == 2 ? -v : v);
+            }
+        }
+    }
+    const int cog = co / nco, col = co - cog * nco, chunk = cq >> 1, quad = cq & 1;
+    float *dst = U + ((((size_t)cog * (C / 8) + chunk) * 20 * 2 + quad) * nco + col) * 4;
+#pragma unroll
+    for (int xi = 0; xi < 20; ++xi) {
+        const f32x4 v = {out[xi][0], out[xi][1], out[xi][2], out[xi][3]};
+        *(f32x4 *)(dst + (size_t)xi * 2 * nco * 4) = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -645,6 +686,17 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
     else
         hipLaunchKernelGGL(k_wino_conv<2>, dim3(rows * 8), dim3(256), lds_bytes, (hipStream_t)stream, dev_x, dev_u, dev_bias,
                            dev_residual, dev_y, batch, channels, flags, n_groups);
+    return xq::launch_status();
+}
+
+int xq_wino_transform_filters(const float *dev_w, float *dev_u, int channels, int flags, void *stream) {
+    if (!dev_w || !dev_u || dev_w == dev_u) return XQ_ERR_ARG;
+    const int nco = (flags & XQ_CONV_WIDE) ? 128 : 64;
+    if (channels < nco || channels % nco || 8 % (channels / nco)) return XQ_ERR_ARG;
+    if (((uintptr_t)dev_w | (uintptr_t)dev_u) & 15) return XQ_ERR_ARG;
+    const int threads = channels * (channels / 4);
+    hipLaunchKernelGGL(k_wino_filter_transform, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_w, dev_u, channels,
+                       nco, (flags & XQ_FILTER_DGRAD) ? 1 : 0);
     return xq::launch_status();
 }
 

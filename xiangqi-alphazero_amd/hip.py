@@ -102,6 +102,11 @@ def lib():
     L.xq_wino_weight_bytes.argtypes = [i32]
     L.xq_wino_weight_bytes.restype = C.c_size_t
     L.xq_wino_conv3x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.xq_wino_transform_filters.argtypes = [vp, vp, i32, i32, vp]
+    L.xq_bn_scratch_bytes.argtypes = [i32]
+    L.xq_bn_scratch_bytes.restype = C.c_size_t
+    L.xq_bn_train_forward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_longlong, i32, i32, vp, vp, vp, vp, vp]
+    L.xq_bn_train_backward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_longlong, i32, i32, vp, vp, vp, vp, vp, vp]
     L.xq_wino_weight_bytes_bf16.argtypes = [i32]
     L.xq_wino_weight_bytes_bf16.restype = C.c_size_t
     L.xq_wino_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
@@ -119,7 +124,8 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_engine_stats_read", "xq_engine_drain", "xq_engine_set_position", "xq_engine_read_root",
            "xq_bias_act", "xq_stem_conv", "xq_heads_1x1", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch",
            "xq_policy_head_legal", "xq_value_head", "xq_engine_requests", "xq_engine_expand_legal", "xq_engine_drain_device",
-           "xq_wino_weight_bytes_bf16", "xq_wino_conv3x3_bf16"]
+           "xq_wino_weight_bytes_bf16", "xq_wino_conv3x3_bf16", "xq_wino_transform_filters",
+           "xq_bn_scratch_bytes", "xq_bn_train_forward", "xq_bn_train_backward"]
 
 
 def check(rc: int, what: str):
@@ -274,6 +280,21 @@ def wino_transform_weights(w: torch.Tensor, co_block: int = 64) -> torch.Tensor:
     u = u.reshape(20, c // co_block, co_block, c // 8, 2, 4)                               # xi, cog, co, chunk, quad, k
     u = u.permute(1, 3, 0, 4, 2, 5).contiguous().to(torch.float32)                         # cog, chunk, xi, quad, co, k
     return u.to(w.device)
+
+
+def wino_transform_filters_device(w: torch.Tensor, co_block: int = 64, dgrad: bool = False, out: torch.Tensor = None) -> torch.Tensor:
+    """`wino_transform_weights` by one kernel launch on the device (xq_wino_transform_filters; the train step re-transforms every
+    optimizer step).  `dgrad=True`: the filters of the data-gradient convolution, w'[co][ci][r][s] = w[ci][co][2-r][2-s]."""
+    c = w.shape[0]
+    if w.shape != (c, c, 3, 3) or w.dtype != torch.float32 or not w.is_cuda or co_block not in (64, 128) or c % co_block \
+            or 8 % (c // co_block):
+        raise XqError("wino_transform_filters_device: float32[C,C,3,3] on the GPU, C a multiple of co_block (64 or 128), C / co_block in {1,2,4,8}")
+    w = w.detach().contiguous()
+    if out is None:
+        out = torch.empty((c // co_block, c // 8, 20, 2, co_block, 4), dtype=torch.float32, device=w.device)
+    check(lib().xq_wino_transform_filters(w.data_ptr(), out.data_ptr(), c, (4 if co_block == 128 else 0) | (8 if dgrad else 0),
+                                          stream_ptr(w.device)), "xq_wino_transform_filters")
+    return out
 
 
 def wino_transform_weights_bf16(w: torch.Tensor) -> torch.Tensor:

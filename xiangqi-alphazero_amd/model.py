@@ -26,10 +26,24 @@ class ResBlock(nn.Module):
         self.bn1 = nn.BatchNorm2d(channels)
         self.conv2 = nn.Conv2d(channels, channels, 3, padding=1, bias=False)
         self.bn2 = nn.BatchNorm2d(channels)
+        # True: on the GPU the two convolutions run on the hand-written Winograd kernel, forward and data gradient
+        # (native_conv.WinoConv3x3); set by XiangqiNet.use_native_conv, never part of the state_dict
+        self.native_conv = False
+
+    def _conv(self, conv: nn.Conv2d, x):
+        if self.native_conv and x.is_cuda and x.dtype == torch.float32:
+            from .native_conv import conv3x3
+            return conv3x3(x, conv.weight)
+        return conv(x)
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
+        if self.native_conv and x.is_cuda and x.dtype == torch.float32:
+            from .native_conv import bn_act, bn_supported
+            if bn_supported(self.bn1) and bn_supported(self.bn2):      # training mode: BatchNorm + ReLU (+ skip) fused, hand-written
+                y = bn_act(self._conv(self.conv1, x), self.bn1, None, True)
+                return bn_act(self._conv(self.conv2, y), self.bn2, x, True)
+        y = F.relu(self.bn1(self._conv(self.conv1, x)))
+        y = self.bn2(self._conv(self.conv2, y))
         return F.relu(y + x)
 
 
@@ -52,9 +66,29 @@ class XiangqiNet(nn.Module):
                                         nn.Linear(VALUE_PLANES * ROWS * COLS, VALUE_HIDDEN), nn.ReLU(),
                                         nn.Linear(VALUE_HIDDEN, 1), nn.Tanh())
 
+    def use_native_conv(self, on: bool = True) -> "XiangqiNet":
+        """Route the residual tower's convolutions of training / eval forwards on the GPU through the hand-written Winograd kernel
+        (forward + data gradient; native_conv.py) and keep the module in channels-last memory, which is that kernel's layout.
+        Results equal torch's convolution to float32 rounding (tests/test_training.py); state_dict keys and shapes do not change."""
+        from .native_conv import supported
+        if on and not supported(self.num_channels):
+            raise ValueError("native convolution needs 64, 128, 256 or 512 channels")
+        for blk in self.res_blocks:
+            blk.native_conv = bool(on)
+        if on:
+            self.to(memory_format=torch.channels_last)
+        return self
+
     def forward(self, x):
         """x f32[B,15,10,9] -> (policy logits f32[B,8100], value f32[B,1])  (model.py:87-107)."""
-        h = self.input_conv(x)
+        h = None
+        if self.res_blocks and self.res_blocks[0].native_conv and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+            from .native_conv import bn_act, bn_supported
+            if bn_supported(self.input_conv[1]):
+                h = bn_act(self.input_conv[0](x), self.input_conv[1], None, True)
+        if h is None:
+            h = self.input_conv(x)
         for blk in self.res_blocks:
             h = blk(h)
         return self.policy_head(h), self.value_head(h)
