@@ -295,6 +295,14 @@ int xq_bn_train_backward(const float *dev_dy, const float *dev_x, const float *d
                          const float *dev_save_invstd, long long rows, int channels, int relu, float *dev_dx, float *dev_dresidual,
                          float *dev_dgamma, float *dev_dbeta, void *dev_scratch, void *stream);
 
+/* Weight gradient of y = conv3x3(x, w) (stride 1, pad 1, C -> C; what torch autograd's convolution_backward returns for
+ * ResBlock.conv1/conv2.weight under training/train.py:376-447), in the Winograd domain of xq_wino_conv3x3 on the fp32 MFMA:
+ *   dev_x, dev_dy : float32[batch][90][channels] (NHWC);  dev_dw : float32[channels][channels][3][3] (torch's layout), overwritten;
+ *   dev_scratch   : xq_wino_wgrad_scratch_bytes(batch, channels) bytes (per-split partial sums, added in a fixed order: deterministic).
+ * channels in {64, 128, 256, 512}. */
+size_t xq_wino_wgrad_scratch_bytes(int batch, int channels);
+int xq_wino_wgrad(const float *dev_x, const float *dev_dy, float *dev_dw, void *dev_scratch, int batch, int channels, void *stream);
+
 /* REDUCED-PRECISION throughput mode of the same convolution (never the parity path; outside the 1e-5 contract): the identical
  * fused Winograd decomposition with the 20 per-frequency products on the bf16 MFMA (operands rounded to bf16 after the float32
  * transforms, float32 accumulation, float32 activations in HBM).  Replaces nothing in the reference -- its own inference is

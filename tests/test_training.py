@@ -69,10 +69,10 @@ def test_device_filter_transform_equals_the_host_transform(channels, co_block):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("channels,batch", [(64, 5), (128, 37), (256, 256)])
+@pytest.mark.parametrize("channels,batch", [(64, 5), (64, 1), (128, 37), (256, 256), (512, 3)])
 def test_native_conv_forward_and_gradients_equal_torch(channels, batch):
-    """native_conv.WinoConv3x3 (forward and data gradient on the hand-written kernel) against torch's convolution in float64 on the
-    same operands: output, dL/dx and dL/dw within 1e-5 of the largest magnitude (float32 Winograd rounding)."""
+    """native_conv.WinoConv3x3 (forward, data gradient and weight gradient on the hand-written kernels) against torch's convolution in
+    float64 on the same operands: output, dL/dx and dL/dw within 1e-5 of the largest magnitude (float32 Winograd rounding)."""
     import torch
     import torch.nn.functional as F
     from xiangqi_alphazero_amd import native_conv

@@ -8,18 +8,16 @@
 //              dx = gamma * invstd * (g - dbeta / rows - xhat * dgamma / rows);  d_residual = g.
 // All of it is HBM/cache-bound streaming over a [rows][C] float32 tensor (23.6 MB at batch 256, C = 256): a thread owns four consecutive
 // channels (16-byte accesses, a wave covers 1 KB of a row), the rows are cut into NSEG contiguous segments (one workgroup each), per-segment
-// sums are float64 and reduced in a fixed order by a one-workgroup finalize kernel -- deterministic, no atomics.  Algorithmic bytes:
+// sums are float64 and reduced in a fixed order by a small finalize kernel -- deterministic, no atomics.  Algorithmic bytes:
 // forward 3 passes (+1 with a residual), backward 7 (+1), of rows * C * 4 bytes.
+#include <type_traits>
+
 #include "xq_common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NSEG = 256;                         // row segments = workgroups of the reduction kernels = one round of the 256 CUs
-
-struct D4 {
-    double v[4];
-};
+constexpr int NSEG = 256;                         // row segments = workgroups of the reduction kernels (one round of the 256 CUs)
 
 // Per-segment partial sums.  MODE 0 (forward): a = sum x, b = sum x^2.  MODE 1 (backward): a = sum g, b = sum g * xhat.
 template <int MODE>
@@ -80,17 +78,39 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ X,
     }
 }
 
-// forward finalize: one thread per channel sums the NSEG partials in order
-__global__ void k_bn_fwd_finalize(const double *__restrict__ part, long long rows, int C, float momentum, float eps,
-                                  float *__restrict__ run_mean, float *__restrict__ run_var, float *__restrict__ save_mean,
-                                  float *__restrict__ save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int j = 0; j < NSEG; ++j) {
-        s += part[(size_t)j * C + c];
-        q += part[(size_t)(NSEG + j) * C + c];
+// Sum of the NSEG partials of 4 channels by one workgroup (C / 4 workgroups): thread (j, c) adds segments j, j + 64, j + 128, j + 192, then a
+// fixed binary tree over the 64 j through LDS -- a fixed summation order, so the result does not depend on scheduling.
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int C, double &s, double &q) {
+    __shared__ double rs[64][4], rq[64][4];
+    const int c = threadIdx.x & 3, j = threadIdx.x >> 2, ch = blockIdx.x * 4 + c;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = j; k < NSEG; k += 64) {
+        a += part[(size_t)k * C + ch];
+        b += part[(size_t)(NSEG + k) * C + ch];
     }
+    rs[j][c] = a;
+    rq[j][c] = b;
+    __syncthreads();
+    for (int w = 32; w >= 1; w >>= 1) {
+        if (j < w) {
+            rs[j][c] += rs[j + w][c];
+            rq[j][c] += rq[j + w][c];
+        }
+        __syncthreads();
+    }
+    s = rs[0][c];
+    q = rq[0][c];
+}
+
+// forward finalize: grid C / 4 workgroups of 256 threads
+__global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restrict__ part, long long rows, int C, float momentum, float eps,
+                                                          float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                          float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+    double s, q;
+    reduce_partials(part, C, s, q);
+    if (threadIdx.x >= 4) return;
+    const int c = blockIdx.x * 4 + threadIdx.x;
     const double n = (double)rows, m = s / n;
     double var = q / n - m * m;
     if (var < 0.0) var = 0.0;
@@ -103,14 +123,12 @@ __global__ void k_bn_fwd_finalize(const double *__restrict__ part, long long row
     }
 }
 
-__global__ void k_bn_bwd_finalize(const double *__restrict__ part, int C, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int j = 0; j < NSEG; ++j) {
-        s += part[(size_t)j * C + c];
-        q += part[(size_t)(NSEG + j) * C + c];
-    }
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restrict__ part, int C, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta) {
+    double s, q;
+    reduce_partials(part, C, s, q);
+    if (threadIdx.x >= 4) return;
+    const int c = blockIdx.x * 4 + threadIdx.x;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
 }
@@ -168,6 +186,237 @@ __global__ __launch_bounds__(256) void k_bn_dx(const float *__restrict__ DY, con
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 convolution in the Winograd domain (the transpose of xq_conv.hip's algorithm):
+//   dW = G_r'^T [ sum over tiles  (A_r dY A_c^T)  (.)  (B_r'^T d B_c') ] G_c'
+// with the SAME matrices as the forward kernel: per output tile (2 x 3) the gradient tile is expanded to the 4 x 5 frequencies (A), the input
+// patch (4 x 5) is transformed as in the forward pass (B'), and for each of the 20 frequencies the products are summed over tiles by the fp32
+// MFMA: M = 32 output channels, N = 32 input channels, K = 2 tiles per instruction -- 300 instead of 810 multiplies per tile and channel pair.
+// A workgroup owns a 64 x 64 block of channel pairs and one contiguous range of tiles (split-K); wave p owns Winograd row p: 5 frequencies x
+// 2 x 2 MFMA tiles = 320 accumulators (15 tiles in AGPRs, 5 pinned to VGPRs, as xq_conv.hip).  Operands come straight from global memory
+// (NHWC: 32 lanes = 32 consecutive channels = 128 B), one tile per half-wave, transformed in registers; board edges are out-of-range buffer
+// offsets (zeros, no traffic).  No LDS and no barrier in the main loop.  Epilogue: the column half of G'^T . G' in registers, the row half
+// across the four waves through LDS, 9 values per channel pair into this split's partial; k_wgrad_reduce adds the splits in order.
+constexpr int WG_ESTR = 72;                                         // LDS row stride of the exchange (floats): half-waves 32 banks apart
+constexpr int WG_LDS_BYTES = 4 * 3 * 32 * WG_ESTR * 4;               // [p][s][32 rows][72] = 110 592
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MT = 4: block of 128 output x 32 input channels (C % 128 == 0): the gradient tile comes by 16-byte loads (lane n: output channels 4 n .. 4 n + 3,
+//         so MFMA tile mt holds the channels = mt mod 4), the input by dword loads: 16 vector-memory instructions per step and wave -- the
+//         texture addresser takes ~16 cycles per wave instruction whatever its width, and with dword loads only (32 per step) it was the bound.
+// MT = 2: block of 64 x 64 channels, dword loads (C = 64).
+template <int MT>
+__global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__ X, const float *__restrict__ DY, float *__restrict__ part,
+                                                        int B, int C, int n_split) {
+    constexpr int NT = 4 / MT, BCO = 32 * MT, BCI = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kp = lane >> 5;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform, and KNOWN uniform: the row offsets below go into SGPRs
+                                                                     // (as a VGPR value every load grew a readfirstlane waterfall loop)
+    const int NBI = C / BCI, nblk = (C / BCO) * NBI;
+    const int total = n_split * nblk;
+    const int L = (int)(blockIdx.x & 7) * (total >> 3) + (int)(blockIdx.x >> 3);       // consecutive logical ids share an XCD (and its L2)
+    const int split = L / nblk, cb = (L % nblk) / NBI, nb = L % NBI;
+    const int T = B * 15, pairs = (T + 1) >> 1, pps = (pairs + n_split - 1) / n_split;
+    const int t_lo = 2 * split * pps, t_hi = t_lo + 2 * pps < T ? t_lo + 2 * pps : T;
+    const unsigned C4 = (unsigned)C * 4u;
+    const unsigned nbytes = (unsigned)B * 90u * C4;
+    // input descriptor starts 10 positions BEFORE the tensor: patch element (rho, c) of the tile at position pos0 is at offset
+    // (pos0 + 9 rho + c) * C4 >= 0; elements before the tensor are exactly the masked ones (never fetched)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)X - 10 * (size_t)C4), 0, (int)(nbytes + 10u * C4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)DY, 0, (int)nbytes, 0x00020000);
+    const unsigned OOB = 0xFFFFF000u;                                // out of range for every tensor the host check admits
+    const float sg = p == 1 ? 1.0f : -1.0f;
+    const int rho_a = p == 0 ? 0 : 1, rho_b = p == 3 ? 3 : 2;
+    const unsigned xch = (unsigned)(nb * BCI + n) * 4u, ych = (unsigned)(cb * BCO + (MT == 4 ? 4 * n : n)) * 4u;
+
+    f32x16 acc[5][4];                                                // [frequency j][tile f = mt * NT + nt]
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][f][e] = 0.0f;
+
+    // operands of TWO steps in flight (stage = step parity): one step of MFMAs (1 280 cycles) does not cover a loaded L2 / Infinity-Cache
+    // round trip
+    float xa_[2][NT][5], xb_[2][NT][5], ya_[2][MT][3], yb_[2][MT][3];
+    auto issue = [&](auto stage_tag, int t) __attribute__((always_inline)) {
+        constexpr int SG = decltype(stage_tag)::value;
+        auto &xa = xa_[SG]; auto &xb = xb_[SG]; auto &ya = ya_[SG]; auto &yb = yb_[SG];
+        const int tau = t + kp;
+        const int b = tau / 15, r = tau - 15 * b, ty = r / 3, tx = r - 3 * ty;
+        const unsigned pos0 = (unsigned)(b * 90 + 18 * ty + 3 * tx);
+        const bool ok = tau < t_hi;
+        const unsigned xv = ok ? pos0 * C4 + xch : OOB, yv = ok ? pos0 * C4 + ych : OOB;
+        const unsigned xv0 = tx > 0 ? xv : OOB, xv4 = tx < 2 ? xv : OOB;
+        const bool ma = p == 0 && ty == 0, mb = p == 3 && ty == 4;
+        const unsigned a1 = ma ? OOB : xv, a0 = ma ? OOB : xv0, a4 = ma ? OOB : xv4;
+        const unsigned b1 = mb ? OOB : xv, b0 = mb ? OOB : xv0, b4 = mb ? OOB : xv4;
+        const unsigned ya_v = p == 3 ? OOB : yv, yb_v = p == 0 ? OOB : yv;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                xa[nt][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, c == 0 ? a0 : c == 4 ? a4 : a1, (unsigned)(rho_a * 9 + c) * C4 + 128u * nt, 0));
+                xb[nt][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, c == 0 ? b0 : c == 4 ? b4 : b1, (unsigned)(rho_b * 9 + c) * C4 + 128u * nt, 0));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (MT == 4) {
+                // (the 8-byte builtin, __builtin_amdgcn_raw_buffer_load_b64, is lowered to a single-dword load by this hipcc: 16 bytes it is)
+                const f32x4 qa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, ya_v, (unsigned)c * C4, 0));
+                const f32x4 qb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, yb_v, (unsigned)(9 + c) * C4, 0));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    ya[mt][c] = qa[mt];
+                    yb[mt][c] = qb[mt];
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    ya[mt][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, ya_v, (unsigned)c * C4 + 128u * mt, 0));
+                    yb[mt][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yb_v, (unsigned)(9 + c) * C4 + 128u * mt, 0));
+                }
+            }
+        }
+    };
+
+    auto step = [&](auto stage_tag, int t) __attribute__((always_inline)) {
+        constexpr int SG = decltype(stage_tag)::value;
+        auto &xa = xa_[SG]; auto &xb = xb_[SG]; auto &ya = ya_[SG]; auto &yb = yb_[SG];
+        float v[NT][5], g[MT][5];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {                           // B_c'^T (B_r'^T d): the forward kernel's formulas
+            float w[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) w[c] = xa[nt][c] + sg * xb[nt][c];
+            const float tt = w[3] - w[1];
+            v[nt][0] = 2.0f * (w[0] - w[2]) + tt;
+            v[nt][1] = 2.0f * w[1] - w[3] + w[2];
+            v[nt][2] = 3.0f * w[2] - (2.0f * w[1] + w[3]);
+            v[nt][3] = tt;
+            v[nt][4] = (w[4] - w[2]) - 2.0f * tt;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {                           // A_c (A_r dY): rows (1,0) (1,1) (1,-1) (0,-1); columns at 0, 1, -1, 2, inf
+            const float a0 = ya[mt][0] + sg * yb[mt][0], a1 = ya[mt][1] + sg * yb[mt][1], a2 = ya[mt][2] + sg * yb[mt][2];
+            const float s02 = a0 + a2;
+            g[mt][0] = a0;
+            g[mt][1] = s02 + a1;
+            g[mt][2] = s02 - a1;
+            g[mt][3] = (a0 + 4.0f * a2) + 2.0f * a1;
+            g[mt][4] = a2;
+        }
+        issue(stage_tag, t + 4);                                    // this stage's registers are free: fetch the step after next (past the
+                                                                    // range: out-of-range offsets, no traffic)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int fo = 0; fo < 4; ++fo) {
+                // the pinned tile's MFMA is inline asm, invisible to the compiler's hazard recogniser.  (a) A vector instruction that writes
+                // one of its source registers must be 2 wait states ahead (the compiler puts s_nop 1 before its own MFMAs; found here as a
+                // deterministic wrong tile): the s_nop travels inside the asm.  (b) It goes FIRST of its group, so three compiler-known
+                // MFMAs separate it from the next step's vector writes to its source registers.
+                const int f = (fo + 3) & 3;
+                const int mt = f / NT, nt = f % NT;
+                if (f == 3)
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j][f]) : "v"(g[mt][j]), "v"(v[nt][j]));
+                else
+                    acc[j][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[mt][j], v[nt][j], acc[j][f], 0, 0, 0);
+            }
+        }
+    };
+    issue(std::integral_constant<int, 0>{}, t_lo);
+    issue(std::integral_constant<int, 1>{}, t_lo + 2);
+    for (int t = t_lo; t < t_hi; t += 4) {                          // a step past t_hi multiplies zeros (every offset out of range)
+        step(std::integral_constant<int, 0>{}, t);
+        step(std::integral_constant<int, 1>{}, t + 2);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[4][3]));        // asm MFMA results -> VALU readers (invisible to the hazard recogniser)
+
+    // ---- epilogue: dW[r][s] = sum_p G_r'[p][r] sum_j G_c'[j][s] acc[j]; column half here, row half across the waves through LDS, two
+    // accumulator tiles (f = 2 h, 2 h + 1) per round: exchange columns 0-31 / 32-63
+    float *E = (float *)lds;
+    const float k6 = 1.0f / 6.0f;
+    const int rrow = tid >> 3, rcol = (tid & 7) * 8, ru = rcol >> 5;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = 2 * h + u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float m0 = acc[0][f][e], m1 = acc[1][f][e], m2 = acc[2][f][e], m3 = acc[3][f][e], m4 = acc[4][f][e];
+                const float h1 = 0.5f * m1;
+                const float c0 = (0.5f * m0 + h1) + k6 * (m2 + m3);
+                const float c1 = h1 + k6 * (2.0f * m3 - m2);
+                const float c2 = (h1 + k6 * (m2 + 4.0f * m3)) + m4;
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kp;
+                float *dst = E + ((p * 3) * 32 + row) * WG_ESTR + u * 32 + n;
+                dst[0] = c0;
+                dst[32 * WG_ESTR] = c1;
+                dst[2 * 32 * WG_ESTR] = c2;
+            }
+        }
+        __syncthreads();
+        // reader: exchange row rrow, columns rcol .. rcol + 7 -> channel pair of the block
+        //   MT = 2 (f = (mt = h, nt = u)): co = 32 h + rrow,          ci = rcol .. (32 u + n)
+        //   MT = 4 (f = mt = 2 h + u):     co = 4 rrow + 2 h + ru,    ci = (rcol & 31) ..
+        const int co_l = MT == 4 ? 4 * rrow + 2 * h + ru : 32 * h + rrow, ci_l = MT == 4 ? (rcol & 31) : rcol;
+        float *out = part + (((size_t)split * 9) * C + (size_t)(cb * BCO + co_l)) * C + nb * BCI + ci_l;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            f32x4 q[4][2];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const float *src = E + ((pp * 3 + s3) * 32 + rrow) * WG_ESTR + rcol;
+                q[pp][0] = *(const f32x4 *)src;
+                q[pp][1] = *(const f32x4 *)(src + 4);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4 r0 = q[0][hh] + 0.5f * (q[1][hh] - q[2][hh]);
+                const f32x4 r1 = 0.5f * (q[1][hh] + q[2][hh]);
+                const f32x4 r2 = 0.5f * (q[1][hh] - q[2][hh]) + q[3][hh];
+                *(f32x4 *)(out + ((size_t)(0 * 3 + s3) * C) * C + 4 * hh) = r0;
+                *(f32x4 *)(out + ((size_t)(1 * 3 + s3) * C) * C + 4 * hh) = r1;
+                *(f32x4 *)(out + ((size_t)(2 * 3 + s3) * C) * C + 4 * hh) = r2;
+            }
+        }
+        if (h == 0) __syncthreads();
+    }
+}
+
+// dW[co][ci][r][s] = sum over splits, in order, of part[split][3 r + s][co][ci]
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ part, float *__restrict__ DW, int C, int n_split) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                    // channel pair co * C + ci
+    if (i >= C * C) return;
+    float o[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = 0.0f;
+    for (int sp = 0; sp < n_split; ++sp)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] += part[((size_t)sp * 9 + k) * C * C + i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) DW[(size_t)i * 9 + k] = o[k];
+}
+
+int wgrad_blocks(int channels) { return channels % 128 == 0 ? (channels / 128) * (channels / 32) : (channels / 64) * (channels / 64); }
+
+int wgrad_splits(int batch, int channels) {
+    const int nblk = wgrad_blocks(channels);
+    const int pairs = (batch * 15 + 1) / 2;
+    int n = 256 / nblk;                                              // one round of the 256 CUs
+    if (n < 1) n = 1;
+    if (n > pairs) n = pairs;
+    while ((n * nblk) % 8) ++n;                                      // the XCD mapping wants a multiple of 8 workgroups
+    return n;
+}
+
 bool bn_args_ok(long long rows, int C) { return rows > 0 && C >= 64 && C <= 1024 && C % 64 == 0 && 256 % (C / 4) == 0; }
 
 }  // namespace
@@ -187,7 +436,7 @@ int xq_bn_train_forward(const float *dev_x, const float *dev_residual, const flo
     hipStream_t s = (hipStream_t)stream;
     double *part = (double *)dev_scratch;
     hipLaunchKernelGGL(k_bn_partial<0>, dim3(NSEG), dim3(256), 0, s, dev_x, nullptr, nullptr, nullptr, nullptr, rows, channels, 0, part);
-    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((channels + 63) / 64), dim3(64), 0, s, part, rows, channels, momentum, eps, dev_running_mean,
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(channels / 4), dim3(256), 0, s, part, rows, channels, momentum, eps, dev_running_mean,
                        dev_running_var, dev_save_mean, dev_save_invstd);
     const long long quads = rows * channels / 4;
     const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
@@ -209,11 +458,40 @@ int xq_bn_train_backward(const float *dev_dy, const float *dev_x, const float *d
     double *part = (double *)dev_scratch;
     hipLaunchKernelGGL(k_bn_partial<1>, dim3(NSEG), dim3(256), 0, s, dev_x, dev_dy, dev_y, dev_save_mean, dev_save_invstd, rows, channels,
                        relu, part);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((channels + 63) / 64), dim3(64), 0, s, part, channels, dev_dgamma, dev_dbeta);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(channels / 4), dim3(256), 0, s, part, channels, dev_dgamma, dev_dbeta);
     const long long quads = rows * channels / 4;
     const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_bn_dx, dim3(grid), dim3(256), 0, s, dev_dy, dev_x, dev_y, dev_gamma, dev_save_mean, dev_save_invstd, dev_dgamma,
                        dev_dbeta, quads, rows, channels, relu, dev_dx, dev_dresidual);
+    return xq::launch_status();
+}
+
+size_t xq_wino_wgrad_scratch_bytes(int batch, int channels) {
+    if (batch <= 0 || channels < 64 || channels % 64) return 0;
+    return (size_t)wgrad_splits(batch, channels) * 9 * channels * channels * sizeof(float);
+}
+
+int xq_wino_wgrad(const float *dev_x, const float *dev_dy, float *dev_dw, void *dev_scratch, int batch, int channels, void *stream) {
+    if (!dev_x || !dev_dy || !dev_dw || !dev_scratch || batch <= 0) return XQ_ERR_ARG;
+    if (channels < 64 || channels % 64 || 8 % (channels / 64)) return XQ_ERR_ARG;
+    if (((uintptr_t)dev_x | (uintptr_t)dev_dy | (uintptr_t)dev_dw | (uintptr_t)dev_scratch) & 15) return XQ_ERR_ARG;
+    if (((unsigned long long)batch * 90ull + 64ull) * (unsigned)channels * 4ull >= 0xFFF00000ull) return XQ_ERR_ARG;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_wgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
+        XQ_TRY(hipFuncSetAttribute((const void *)k_wino_wgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
+        attr_set = true;
+    }
+    const int n_split = wgrad_splits(batch, channels);
+    const int nblk = wgrad_blocks(channels);
+    if (channels % 128 == 0)
+        hipLaunchKernelGGL(k_wino_wgrad<4>, dim3(n_split * nblk), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, dev_x, dev_dy,
+                           (float *)dev_scratch, batch, channels, n_split);
+    else
+        hipLaunchKernelGGL(k_wino_wgrad<2>, dim3(n_split * nblk), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, dev_x, dev_dy,
+                           (float *)dev_scratch, batch, channels, n_split);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((channels * channels + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)dev_scratch, dev_dw, channels, n_split);
     return xq::launch_status();
 }
 

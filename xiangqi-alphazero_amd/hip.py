@@ -103,6 +103,9 @@ def lib():
     L.xq_wino_weight_bytes.restype = C.c_size_t
     L.xq_wino_conv3x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.xq_wino_transform_filters.argtypes = [vp, vp, i32, i32, vp]
+    L.xq_wino_wgrad_scratch_bytes.argtypes = [i32, i32]
+    L.xq_wino_wgrad_scratch_bytes.restype = C.c_size_t
+    L.xq_wino_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.xq_bn_scratch_bytes.argtypes = [i32]
     L.xq_bn_scratch_bytes.restype = C.c_size_t
     L.xq_bn_train_forward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_longlong, i32, i32, vp, vp, vp, vp, vp]
@@ -125,7 +128,7 @@ EXPORTS = ["xq_version", "xq_last_hip_error", "xq_movegen_batch", "xq_attack_map
            "xq_bias_act", "xq_stem_conv", "xq_heads_1x1", "xq_wino_weight_bytes", "xq_wino_conv3x3", "xq_samples_to_batch",
            "xq_policy_head_legal", "xq_value_head", "xq_engine_requests", "xq_engine_expand_legal", "xq_engine_drain_device",
            "xq_wino_weight_bytes_bf16", "xq_wino_conv3x3_bf16", "xq_wino_transform_filters",
-           "xq_bn_scratch_bytes", "xq_bn_train_forward", "xq_bn_train_backward"]
+           "xq_bn_scratch_bytes", "xq_bn_train_forward", "xq_bn_train_backward", "xq_wino_wgrad_scratch_bytes", "xq_wino_wgrad"]
 
 
 def check(rc: int, what: str):
@@ -295,6 +298,21 @@ def wino_transform_filters_device(w: torch.Tensor, co_block: int = 64, dgrad: bo
     check(lib().xq_wino_transform_filters(w.data_ptr(), out.data_ptr(), c, (4 if co_block == 128 else 0) | (8 if dgrad else 0),
                                           stream_ptr(w.device)), "xq_wino_transform_filters")
     return out
+
+
+def wino_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of the 3x3 convolution (xq_wino_wgrad): x, dy float32[B, 90, C] contiguous -> float32[C, C, 3, 3]."""
+    b, n, c = x.shape
+    if n != 90 or dy.shape != x.shape or x.dtype != torch.float32 or dy.dtype != torch.float32 or not x.is_contiguous() \
+            or not dy.is_contiguous() or not x.is_cuda:
+        raise XqError("wino_wgrad: float32[B,90,C] contiguous tensors on the GPU required")
+    nbytes = lib().xq_wino_wgrad_scratch_bytes(b, c)
+    if nbytes == 0:
+        raise XqError("wino_wgrad: channels must be 64, 128, 256 or 512")
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib().xq_wino_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), b, c, stream_ptr(x.device)), "xq_wino_wgrad")
+    return dw
 
 
 def wino_transform_weights_bf16(w: torch.Tensor) -> torch.Tensor:

@@ -5,8 +5,8 @@ trains through torch.nn.Conv2d, training/train.py:376-447 over model.py:20-36).
   * forward: `xq_wino_conv3x3` on the NHWC view of a channels-last tensor (no copy), filters transformed on the device
     (`xq_wino_transform_filters`);
   * data gradient: the same kernel on dL/dy with the transposed, 180-degree-rotated filters (XQ_FILTER_DGRAD);
-  * weight gradient: the ROCm library (`aten::convolution_backward`, weight mask only) -- a Winograd-domain weight gradient was
-    costed and not built.
+  * weight gradient: `xq_wino_wgrad` -- the transposed algorithm in the same Winograd domain, summed over tiles on the fp32 MFMA
+    (csrc/xq_train.hip).
 `BnAct.apply(...)` / `bn_act(x, bn, residual, relu)` is BatchNorm2d in TRAINING mode fused with the ReLU and the skip-add that follow it in a
 ResBlock (`xq_bn_train_forward` / `xq_bn_train_backward`, csrc/xq_train.hip): batch statistics and every reduction of the backward pass in
 float64 partial sums reduced in a fixed order, running statistics updated in place as torch.nn.BatchNorm2d does.
@@ -72,9 +72,12 @@ class WinoConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _conv(_nhwc(gy), w, True)
         if ctx.needs_input_grad[1]:
-            gy_cl = gy.contiguous(memory_format=torch.channels_last)
-            gw = torch.ops.aten.convolution_backward(gy_cl, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1]
+            if os.environ.get("XQ_TRAIN_WGRAD", "native") == "library":      # A/B runs only
+                gy_cl = gy.contiguous(memory_format=torch.channels_last)
+                gw = torch.ops.aten.convolution_backward(gy_cl, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
+            else:
+                gw = hip.wino_wgrad(_nhwc(x), _nhwc(gy))
         return gx, gw
 
 
