@@ -276,13 +276,17 @@ int xq_wino_conv3x3(const float *dev_x, const float *dev_u, const float *dev_bia
  *   convolution are produced, w'[co][ci][r][s] = w[ci][co][2-r][2-s]: xq_wino_conv3x3(dL/dy, u', 0-bias) is dL/dx of
  *   y = conv3x3(x, w) (stride 1, pad 1) -- what torch autograd's convolution_backward computes for ResBlock.conv1/conv2. */
 #define XQ_FILTER_DGRAD 8
+/* XQ_FILTER_BOTH: forward filters into dev_u[0 .. 20 C^2) and data-gradient filters into dev_u[20 C^2 .. 40 C^2) (floats) in one launch;
+ * dev_u then holds 2 * xq_wino_weight_bytes(C) bytes. */
+#define XQ_FILTER_BOTH 16
 int xq_wino_transform_filters(const float *dev_w, float *dev_u, int channels, int flags, void *stream);
 
 /* BatchNorm2d in TRAINING mode fused with the ReLU / skip-add around it in a ResBlock (training/model.py:20-36: bn1 + relu, bn2 + add +
  * relu; trained by training/train.py:376-447), on NHWC activations float32[rows][channels], rows = batch * 90:
  *   forward :  y = act((x - mean) * invstd * gamma + beta (+ residual)) with the batch statistics of the rows (biased variance);
  *              running_mean / running_var (nullable pair) updated as torch.nn.BatchNorm2d does (momentum, unbiased variance);
- *              save_mean / save_invstd float32[channels] are kept for the backward call.  relu: 0 / 1.
+ *              save_mean / save_invstd float32[channels] are kept for the backward call; dev_batches_tracked (nullable): the module's
+ *              int64 num_batches_tracked, incremented by one.  relu: 0 / 1.
  *   backward:  g = dy * (y > 0) if relu;  dbeta = sum g;  dgamma = sum g * xhat;  dx = gamma * invstd * (g - dbeta / rows - xhat * dgamma / rows);
  *              dev_dresidual (nullable) receives g, the gradient of the skip input.
  * Sums are float64 per row segment, reduced in a fixed order (deterministic).  dev_scratch: xq_bn_scratch_bytes(channels) bytes.
@@ -290,7 +294,8 @@ int xq_wino_transform_filters(const float *dev_w, float *dev_u, int channels, in
 size_t xq_bn_scratch_bytes(int channels);
 int xq_bn_train_forward(const float *dev_x, const float *dev_residual, const float *dev_gamma, const float *dev_beta,
                         float *dev_running_mean, float *dev_running_var, float momentum, float eps, long long rows, int channels,
-                        int relu, float *dev_y, float *dev_save_mean, float *dev_save_invstd, void *dev_scratch, void *stream);
+                        int relu, float *dev_y, float *dev_save_mean, float *dev_save_invstd, long long *dev_batches_tracked,
+                        void *dev_scratch, void *stream);
 int xq_bn_train_backward(const float *dev_dy, const float *dev_x, const float *dev_y, const float *dev_gamma, const float *dev_save_mean,
                          const float *dev_save_invstd, long long rows, int channels, int relu, float *dev_dx, float *dev_dresidual,
                          float *dev_dgamma, float *dev_dbeta, void *dev_scratch, void *stream);

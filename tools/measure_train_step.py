@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--cpu-batches", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--fused-adam", type=int, default=1, help="torch.optim.Adam(fused=True), as train_loop.AlphaZeroLoop builds it on the GPU")
     ap.add_argument("--native-conv", type=int, default=1, help="1: tower convolutions (forward + data gradient) on the hand-written "
                     "Winograd kernel (XiangqiNet.use_native_conv); 0: torch autograd on the ROCm library throughout")
     a = ap.parse_args()
@@ -46,7 +47,7 @@ def main():
     net.load_state_dict(weights.make_state_dict(a.channels, a.blocks))
     net = net.cuda()
     net.use_native_conv(bool(a.native_conv))
-    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-4, fused=bool(a.fused_adam))   # as AlphaZeroLoop builds it
     sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[50, 80], gamma=0.1)
     tcfg = types.SimpleNamespace(min_buffer_size=1, num_epochs=1, batch_size=a.batch)
     training.train_network(net, opt, sch, buf, tcfg)                      # warm-up epoch (allocator, MIOpen find)
@@ -88,7 +89,7 @@ def main():
         "gpu_path": "device-resident compact buffer + xq_samples_to_batch + torch autograd (fp32); tower convolutions: "
                     + ("forward and data gradient on xq_wino_conv3x3 (channels-last), weight gradient ROCm library" if a.native_conv
                        else "ROCm library"),
-        "native_conv": bool(a.native_conv),
+        "native_conv": bool(a.native_conv), "fused_adam": bool(a.fused_adam),
         "cpu_samples_per_s": round(done / cpu_s, 1), "cpu_threads": torch.get_num_threads(), "cpu_samples_timed": done,
         "cpu_path": "the reference's train step restated (train.py:398-419), dense tuples, torch CPU",
         "policy_loss": stats.get("policy_loss")}))

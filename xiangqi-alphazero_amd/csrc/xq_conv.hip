@@ -617,10 +617,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void k_wino_conv(const float 
 // Filter transform on the device (train step: the filters change every optimizer step).  One thread = one output channel x four input
 // channels: 20 float4 stores, coalesced over the output channel.  float64 arithmetic as the host transform (hip.wino_transform_weights),
 // rounded once to float32.  `dgrad`: the filters of the data-gradient convolution, w'[co][ci][r][s] = w[ci][co][2 - r][2 - s].
-__global__ __launch_bounds__(256) void k_wino_filter_transform(const float *__restrict__ W, float *__restrict__ U, int C, int nco, int dgrad) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= C * (C / 4)) return;
-    const int co = t % C, cq = t / C;
+__device__ __forceinline__ void filter_transform_one(const float *__restrict__ W, float *__restrict__ U, int C, int nco, int dgrad, int co, int cq) {
     const double gr[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     const double gc[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6.0, -1.0 / 6.0, 1.0 / 6.0}, {1.0 / 6.0, 2.0 / 6.0, 4.0 / 6.0}, {0.0, 0.0, 1.0}};
     float out[20][4];
@@ -652,6 +649,16 @@ __global__ __launch_bounds__(256) void k_wino_filter_transform(const float *__re
         const f32x4 v = {out[xi][0], out[xi][1], out[xi][2], out[xi][3]};
         *(f32x4 *)(dst + (size_t)xi * 2 * nco * 4) = v;
     }
+}
+
+// mode 0: forward filters; 1: data-gradient filters; 2: both, the data-gradient tensor right behind the forward one (one launch per layer
+// and train step instead of two)
+__global__ __launch_bounds__(256) void k_wino_filter_transform(const float *__restrict__ W, float *__restrict__ U, int C, int nco, int mode) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= C * (C / 4)) return;
+    const int co = t % C, cq = t / C;
+    if (mode != 1) filter_transform_one(W, U, C, nco, 0, co, cq);
+    if (mode != 0) filter_transform_one(W, mode == 2 ? U + (size_t)20 * C * C : U, C, nco, 1, co, cq);
 }
 
 }  // namespace
@@ -696,7 +703,7 @@ int xq_wino_transform_filters(const float *dev_w, float *dev_u, int channels, in
     if (((uintptr_t)dev_w | (uintptr_t)dev_u) & 15) return XQ_ERR_ARG;
     const int threads = channels * (channels / 4);
     hipLaunchKernelGGL(k_wino_filter_transform, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_w, dev_u, channels,
-                       nco, (flags & XQ_FILTER_DGRAD) ? 1 : 0);
+                       nco, (flags & XQ_FILTER_BOTH) ? 2 : (flags & XQ_FILTER_DGRAD) ? 1 : 0);
     return xq::launch_status();
 }
 

@@ -17,7 +17,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NSEG = 256;                         // row segments = workgroups of the reduction kernels (one round of the 256 CUs)
+constexpr int NSEG = 512;                         // row segments = workgroups of the reduction kernels (two per CU)
 
 // Per-segment partial sums.  MODE 0 (forward): a = sum x, b = sum x^2.  MODE 1 (backward): a = sum g, b = sum g * xhat.
 template <int MODE>
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ X,
         mu = *(const f32x4 *)(mean + 4 * tc);
         is = *(const f32x4 *)(invstd + 4 * tc);
     }
+#pragma unroll 4
     for (long long r = lo + tr; r < hi; r += rp) {
         const size_t o = (size_t)r * C + 4 * tc;
         const f32x4 x = *(const f32x4 *)(X + o);
@@ -85,7 +86,7 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
     const int c = threadIdx.x & 3, j = threadIdx.x >> 2, ch = blockIdx.x * 4 + c;
     double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int k = j; k < NSEG; k += 64) {
+    for (int k = j; k < NSEG; k += 64) {                            // NSEG / 64 partials per thread
         a += part[(size_t)k * C + ch];
         b += part[(size_t)(NSEG + k) * C + ch];
     }
@@ -106,9 +107,11 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 // forward finalize: grid C / 4 workgroups of 256 threads
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restrict__ part, long long rows, int C, float momentum, float eps,
                                                           float *__restrict__ run_mean, float *__restrict__ run_var,
-                                                          float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+                                                          float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                          long long *__restrict__ batches_tracked) {
     double s, q;
     reduce_partials(part, C, s, q);
+    if (batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;    // BatchNorm2d.num_batches_tracked
     if (threadIdx.x >= 4) return;
     const int c = blockIdx.x * 4 + threadIdx.x;
     const double n = (double)rows, m = s / n;
@@ -243,13 +246,29 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__
     // operands of TWO steps in flight (stage = step parity): one step of MFMAs (1 280 cycles) does not cover a loaded L2 / Infinity-Cache
     // round trip
     float xa_[2][NT][5], xb_[2][NT][5], ya_[2][MT][3], yb_[2][MT][3];
+    int r15_[2];                                                     // tile-in-board (0..14) of the stage's NEXT issue, this lane's tile
+    unsigned bbase_[2];                                              // 90 * board of it
+#pragma unroll
+    for (int sgi = 0; sgi < 2; ++sgi) {
+        const int tau0 = t_lo + 2 * sgi + kp, b0 = tau0 / 15;
+        r15_[sgi] = tau0 - 15 * b0;
+        bbase_[sgi] = 90u * (unsigned)b0;
+    }
     auto issue = [&](auto stage_tag, int t) __attribute__((always_inline)) {
         constexpr int SG = decltype(stage_tag)::value;
         auto &xa = xa_[SG]; auto &xb = xb_[SG]; auto &ya = ya_[SG]; auto &yb = yb_[SG];
         const int tau = t + kp;
-        const int b = tau / 15, r = tau - 15 * b, ty = r / 3, tx = r - 3 * ty;
-        const unsigned pos0 = (unsigned)(b * 90 + 18 * ty + 3 * tx);
+        // tile -> (board, ty, tx): each stage advances by 4 tiles per call, so board and tile-in-board are carried, not divided out
+        int &r = r15_[SG];
+        unsigned &bb = bbase_[SG];
+        const int ty = (r * 11) >> 5, tx = r - 3 * ty;               // r / 3 for r < 32
+        const unsigned pos0 = bb + (unsigned)(18 * ty + 3 * tx);
         const bool ok = tau < t_hi;
+        r += 4;
+        if (r >= 15) {
+            r -= 15;
+            bb += 90u;
+        }
         const unsigned xv = ok ? pos0 * C4 + xch : OOB, yv = ok ? pos0 * C4 + ych : OOB;
         const unsigned xv0 = tx > 0 ? xv : OOB, xv4 = tx < 2 ? xv : OOB;
         const bool ma = p == 0 && ty == 0, mb = p == 3 && ty == 4;
@@ -293,22 +312,25 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__
         for (int nt = 0; nt < NT; ++nt) {                           // B_c'^T (B_r'^T d): the forward kernel's formulas
             float w[5];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) w[c] = xa[nt][c] + sg * xb[nt][c];
+            // products by +-1, 2 and 4 are exact, so these fused multiply-adds round exactly as the separate multiply and add of the
+            // forward kernel's formulas do (one vector instruction instead of two; the fp32 MFMA shares the vector ALU)
+            for (int c = 0; c < 5; ++c) w[c] = __builtin_fmaf(sg, xb[nt][c], xa[nt][c]);
             const float tt = w[3] - w[1];
-            v[nt][0] = 2.0f * (w[0] - w[2]) + tt;
-            v[nt][1] = 2.0f * w[1] - w[3] + w[2];
-            v[nt][2] = 3.0f * w[2] - (2.0f * w[1] + w[3]);
+            v[nt][0] = __builtin_fmaf(2.0f, w[0] - w[2], tt);
+            v[nt][1] = __builtin_fmaf(2.0f, w[1], -w[3]) + w[2];
+            v[nt][2] = 3.0f * w[2] - __builtin_fmaf(2.0f, w[1], w[3]);
             v[nt][3] = tt;
-            v[nt][4] = (w[4] - w[2]) - 2.0f * tt;
+            v[nt][4] = __builtin_fmaf(-2.0f, tt, w[4] - w[2]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {                           // A_c (A_r dY): rows (1,0) (1,1) (1,-1) (0,-1); columns at 0, 1, -1, 2, inf
-            const float a0 = ya[mt][0] + sg * yb[mt][0], a1 = ya[mt][1] + sg * yb[mt][1], a2 = ya[mt][2] + sg * yb[mt][2];
+            const float a0 = __builtin_fmaf(sg, yb[mt][0], ya[mt][0]), a1 = __builtin_fmaf(sg, yb[mt][1], ya[mt][1]),
+                        a2 = __builtin_fmaf(sg, yb[mt][2], ya[mt][2]);
             const float s02 = a0 + a2;
             g[mt][0] = a0;
             g[mt][1] = s02 + a1;
             g[mt][2] = s02 - a1;
-            g[mt][3] = (a0 + 4.0f * a2) + 2.0f * a1;
+            g[mt][3] = __builtin_fmaf(2.0f, a1, __builtin_fmaf(4.0f, a2, a0));
             g[mt][4] = a2;
         }
         issue(stage_tag, t + 4);                                    // this stage's registers are free: fetch the step after next (past the
@@ -427,7 +449,8 @@ size_t xq_bn_scratch_bytes(int channels) { return (size_t)2 * NSEG * channels * 
 
 int xq_bn_train_forward(const float *dev_x, const float *dev_residual, const float *dev_gamma, const float *dev_beta,
                         float *dev_running_mean, float *dev_running_var, float momentum, float eps, long long rows, int channels,
-                        int relu, float *dev_y, float *dev_save_mean, float *dev_save_invstd, void *dev_scratch, void *stream) {
+                        int relu, float *dev_y, float *dev_save_mean, float *dev_save_invstd, long long *dev_batches_tracked,
+                        void *dev_scratch, void *stream) {
     if (!dev_x || !dev_gamma || !dev_beta || !dev_y || !dev_save_mean || !dev_save_invstd || !dev_scratch) return XQ_ERR_ARG;
     if (!bn_args_ok(rows, channels) || (dev_running_mean == nullptr) != (dev_running_var == nullptr)) return XQ_ERR_ARG;
     if (((uintptr_t)dev_x | (uintptr_t)dev_residual | (uintptr_t)dev_y | (uintptr_t)dev_gamma | (uintptr_t)dev_beta |
@@ -437,7 +460,7 @@ int xq_bn_train_forward(const float *dev_x, const float *dev_residual, const flo
     double *part = (double *)dev_scratch;
     hipLaunchKernelGGL(k_bn_partial<0>, dim3(NSEG), dim3(256), 0, s, dev_x, nullptr, nullptr, nullptr, nullptr, rows, channels, 0, part);
     hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(channels / 4), dim3(256), 0, s, part, rows, channels, momentum, eps, dev_running_mean,
-                       dev_running_var, dev_save_mean, dev_save_invstd);
+                       dev_running_var, dev_save_mean, dev_save_invstd, dev_batches_tracked);
     const long long quads = rows * channels / 4;
     const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(256), 0, s, dev_x, dev_residual, dev_gamma, dev_beta, dev_save_mean, dev_save_invstd,

@@ -108,7 +108,7 @@ def lib():
     L.xq_wino_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.xq_bn_scratch_bytes.argtypes = [i32]
     L.xq_bn_scratch_bytes.restype = C.c_size_t
-    L.xq_bn_train_forward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_longlong, i32, i32, vp, vp, vp, vp, vp]
+    L.xq_bn_train_forward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_longlong, i32, i32, vp, vp, vp, vp, vp, vp]
     L.xq_bn_train_backward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_longlong, i32, i32, vp, vp, vp, vp, vp, vp]
     L.xq_wino_weight_bytes_bf16.argtypes = [i32]
     L.xq_wino_weight_bytes_bf16.restype = C.c_size_t
@@ -285,17 +285,20 @@ def wino_transform_weights(w: torch.Tensor, co_block: int = 64) -> torch.Tensor:
     return u.to(w.device)
 
 
-def wino_transform_filters_device(w: torch.Tensor, co_block: int = 64, dgrad: bool = False, out: torch.Tensor = None) -> torch.Tensor:
+def wino_transform_filters_device(w: torch.Tensor, co_block: int = 64, dgrad: bool = False, out: torch.Tensor = None,
+                                  both: bool = False) -> torch.Tensor:
     """`wino_transform_weights` by one kernel launch on the device (xq_wino_transform_filters; the train step re-transforms every
-    optimizer step).  `dgrad=True`: the filters of the data-gradient convolution, w'[co][ci][r][s] = w[ci][co][2-r][2-s]."""
+    optimizer step).  `dgrad=True`: the filters of the data-gradient convolution, w'[co][ci][r][s] = w[ci][co][2-r][2-s].
+    `both=True`: one launch, returns a [2, ...] tensor -- [0] the forward filters, [1] the data-gradient filters."""
     c = w.shape[0]
     if w.shape != (c, c, 3, 3) or w.dtype != torch.float32 or not w.is_cuda or co_block not in (64, 128) or c % co_block \
             or 8 % (c // co_block):
         raise XqError("wino_transform_filters_device: float32[C,C,3,3] on the GPU, C a multiple of co_block (64 or 128), C / co_block in {1,2,4,8}")
     w = w.detach().contiguous()
+    shape = (c // co_block, c // 8, 20, 2, co_block, 4)
     if out is None:
-        out = torch.empty((c // co_block, c // 8, 20, 2, co_block, 4), dtype=torch.float32, device=w.device)
-    check(lib().xq_wino_transform_filters(w.data_ptr(), out.data_ptr(), c, (4 if co_block == 128 else 0) | (8 if dgrad else 0),
+        out = torch.empty(((2,) + shape) if both else shape, dtype=torch.float32, device=w.device)
+    check(lib().xq_wino_transform_filters(w.data_ptr(), out.data_ptr(), c, (4 if co_block == 128 else 0) | (16 if both else 8 if dgrad else 0),
                                           stream_ptr(w.device)), "xq_wino_transform_filters")
     return out
 

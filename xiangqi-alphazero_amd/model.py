@@ -77,6 +77,14 @@ class XiangqiNet(nn.Module):
             blk.native_conv = bool(on)
         if on:
             self.to(memory_format=torch.channels_last)
+            # ... except the tower's 3x3 filters: the hand-written kernels read and write them as plain [C, C, 3, 3] (a channels-last
+            # parameter would be copied to that layout in every filter transform, and its gradient copied back)
+            with torch.no_grad():
+                for blk in self.res_blocks:
+                    for conv in (blk.conv1, blk.conv2):
+                        conv.weight.data = conv.weight.data.contiguous()
+                        if conv.weight.grad is not None:
+                            conv.weight.grad = conv.weight.grad.contiguous()
         return self
 
     def forward(self, x):

@@ -41,12 +41,11 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
     return v.view(t.shape[0], 90, t.shape[1])
 
 
-def _conv(x_nhwc: torch.Tensor, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+def _conv(x_nhwc: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     b, _, c = x_nhwc.shape
     key = (x_nhwc.device, c)
     if key not in _zero_bias:
         _zero_bias[key] = torch.zeros(c, dtype=torch.float32, device=x_nhwc.device)
-    u = hip.wino_transform_filters_device(w, _co_block(b, c), dgrad)
     out = torch.empty_like(x_nhwc)
     hip.wino_conv3x3(x_nhwc, u, _zero_bias[key], out, None, relu=False)
     return out.view(b, 10, 9, c).permute(0, 3, 1, 2)                      # logical NCHW over channels-last memory
@@ -62,15 +61,19 @@ class WinoConv3x3(torch.autograd.Function):
         if not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or x.shape[2:] != (10, 9) \
                 or w.shape != (x.shape[1], x.shape[1], 3, 3) or not supported(x.shape[1]):
             raise hip.XqError("WinoConv3x3: float32 [B, C, 10, 9] on the GPU with C in {64, 128, 256, 512} and [C, C, 3, 3] filters")
-        ctx.save_for_backward(x, w)
-        return _conv(_nhwc(x), w, False)
+        xv = _nhwc(x)
+        need_dx = ctx.needs_input_grad[0]
+        # forward and data-gradient filters from ONE transform launch when the input needs a gradient (every tower layer does)
+        u = hip.wino_transform_filters_device(w, _co_block(x.shape[0], x.shape[1]), both=need_dx)
+        ctx.save_for_backward(x, w, u[1] if need_dx else u)
+        return _conv(xv, u[0] if need_dx else u)
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
-        x, w = ctx.saved_tensors
+        x, w, u_bwd = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv(_nhwc(gy), w, True)
+            gx = _conv(_nhwc(gy), u_bwd)
         if ctx.needs_input_grad[1]:
             if os.environ.get("XQ_TRAIN_WGRAD", "native") == "library":      # A/B runs only
                 gy_cl = gy.contiguous(memory_format=torch.channels_last)
@@ -89,7 +92,7 @@ class BnAct(torch.autograd.Function):
     """y = act(batch_norm_train(x) (+ residual)); x, residual, y logical [B, C, 10, 9] over channels-last memory."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum: float, eps: float, relu: bool):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum: float, eps: float, relu: bool, batches_tracked=None):
         if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
             raise hip.XqError("BnAct: float32 [B, C, H, W] on the GPU")
         b, c, h, w = x.shape
@@ -108,6 +111,7 @@ class BnAct(torch.autograd.Function):
                                                 None if running_mean is None else running_mean.data_ptr(),
                                                 None if running_var is None else running_var.data_ptr(), float(momentum), float(eps),
                                                 b * h * w, c, int(relu), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                None if batches_tracked is None else batches_tracked.data_ptr(),
                                                 scratch.data_ptr(), hip.stream_ptr(x.device)), "xq_bn_train_forward")
         ctx.relu, ctx.has_res = bool(relu), residual is not None
         ctx.save_for_backward(xv, y, gamma_c, mean, invstd)
@@ -127,7 +131,7 @@ class BnAct(torch.autograd.Function):
                                                  invstd.data_ptr(), b * h * w, c, int(ctx.relu), dx.data_ptr(),
                                                  None if dres is None else dres.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                  scratch.data_ptr(), hip.stream_ptr(xv.device)), "xq_bn_train_backward")
-        return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None)
+        return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None)
 
 
 def bn_supported(bn: torch.nn.Module) -> bool:
@@ -139,5 +143,7 @@ def bn_supported(bn: torch.nn.Module) -> bool:
 
 def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, residual=None, relu: bool = True) -> torch.Tensor:
     """`relu(bn(x) + residual)` of a training-mode forward through the fused kernels; `num_batches_tracked` advances as in torch."""
-    bn.num_batches_tracked.add_(1)
-    return BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu)
+    nbt = bn.num_batches_tracked                                        # incremented inside the statistics kernel (no launch of its own)
+    if nbt.dtype != torch.int64 or not nbt.is_cuda:
+        raise hip.XqError("bn_act: num_batches_tracked must be an int64 tensor on the GPU")
+    return BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, nbt)

@@ -52,8 +52,15 @@ class AlphaZeroLoop:
         torch.manual_seed(seed)                        # identical initial weights on every rank
         self.current_model = XiangqiNet(config.num_channels, config.num_res_blocks).to(self.device)
         self.best_model = copy.deepcopy(self.current_model)
+        on_gpu = self.device.type == "cuda"
+        from . import native_conv
+        if on_gpu and native_conv.supported(config.num_channels):
+            # train step on the hand-written kernels: tower convolutions (forward, data and weight gradient) and the fused
+            # training-mode BatchNorm (native_conv.py); the deep copy above -- the self-play / arena model -- is not touched
+            self.current_model.use_native_conv(True)
+        # fused=True: the whole Adam update in one launch instead of torch's five foreach launches (same formula)
         self.optimizer = torch.optim.Adam(self.current_model.parameters(), lr=config.learning_rate,
-                                          weight_decay=config.weight_decay)
+                                          weight_decay=config.weight_decay, **({"fused": True} if on_gpu else {}))
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=config.lr_milestones,
                                                               gamma=config.lr_gamma)
         self.buffer = training.ReplayBuffer(config.max_buffer_size, self.device)
