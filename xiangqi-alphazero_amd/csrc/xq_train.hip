@@ -196,9 +196,9 @@ __global__ __launch_bounds__(256) void k_bn_dx(const float *__restrict__ DY, con
 // with the SAME matrices as the forward kernel: per output tile (2 x 3) the gradient tile is expanded to the 4 x 5 frequencies (A), the input
 // patch (4 x 5) is transformed as in the forward pass (B'), and for each of the 20 frequencies the products are summed over tiles by the fp32
 // MFMA: M = 32 output channels, N = 32 input channels, K = 2 tiles per instruction -- 300 instead of 810 multiplies per tile and channel pair.
-// A workgroup owns a 64 x 64 block of channel pairs and one contiguous range of tiles (split-K); wave p owns Winograd row p: 5 frequencies x
-// 2 x 2 MFMA tiles = 320 accumulators (15 tiles in AGPRs, 5 pinned to VGPRs, as xq_conv.hip).  Operands come straight from global memory
-// (NHWC: 32 lanes = 32 consecutive channels = 128 B), one tile per half-wave, transformed in registers; board edges are out-of-range buffer
+// A workgroup owns a 128 x 32 (or 64 x 64) block of channel pairs and one contiguous range of tiles (split-K); wave p owns Winograd row p:
+// 5 frequencies x 4 MFMA tiles = 320 accumulators (15 tiles in AGPRs, 5 pinned to VGPRs, as xq_conv.hip).  Operands come straight from global
+// memory (NHWC: channels contiguous), one tile per half-wave, two steps in flight, transformed in registers; board edges are out-of-range buffer
 // offsets (zeros, no traffic).  No LDS and no barrier in the main loop.  Epilogue: the column half of G'^T . G' in registers, the row half
 // across the four waves through LDS, 9 values per channel pair into this split's partial; k_wgrad_reduce adds the splits in order.
 constexpr int WG_ESTR = 72;                                         // LDS row stride of the exchange (floats): half-waves 32 banks apart

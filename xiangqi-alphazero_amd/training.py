@@ -141,7 +141,9 @@ def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shu
         raise hip.XqError("train_network(ddp=False): the model still carries SyncBatchNorm from a ddp step and the process "
                           "group has %d ranks; train with ddp=True on every rank or call revert_sync_batchnorm(model) first"
                           % dist.get_world_size(group))
-    total_p = total_v = 0.0
+    # the two losses of every batch are added up ON THE DEVICE in float64 (the same additions, in the same order, as the reference's
+    # Python floats, train.py:421-423) and read once at the end: no host synchronisation inside the epoch loop
+    totals = torch.zeros(2, dtype=torch.float64, device=buffer.device)
     batches = 0
     for _ in range(config.num_epochs):
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
@@ -170,10 +172,10 @@ def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shu
             pv = torch.stack([policy_loss.detach(), value_loss.detach()])
             if use_ddp and full >= world:
                 dist.all_reduce(pv, group=group)                       # the slices' shares add up to the batch's losses
-            total_p += pv[0].item()
-            total_v += pv[1].item()
+            totals += pv.double()
             batches += 1
     scheduler.step()
+    total_p, total_v = totals.tolist()
     return {"policy_loss": total_p / max(batches, 1), "value_loss": total_v / max(batches, 1),
             "total_loss": (total_p + total_v) / max(batches, 1), "learning_rate": optimizer.param_groups[0]["lr"]}
 
