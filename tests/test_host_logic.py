@@ -375,3 +375,15 @@ def test_bench_workload_label_follows_the_arguments():
     assert "PEAKED" in b.workload_label(mk(8192, 800, 256, 10, True))
     flops, tower = b.net_flops(256, 10)
     assert abs(flops / 1e6 - 2178.0) < 0.5 and abs(b.net_flops(128, 6)[0] / 1e6 - 369.2) < 0.5
+
+
+def test_inline_asm_mfmas_keep_their_wait_states():
+    """tools/check_asm_mfma_hazards.py: every MFMA issued through inline asm (accumulator tiles pinned to VGPRs) either carries its own
+    s_nop or has no vector write of its A/B source registers within the two instructions in front of it in the gfx950 assembly the
+    current compiler produces (the compiler pads only the MFMAs it can see)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_mfma_hazards.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "xq_conv.hip" in r.stdout and "xq_train.hip" in r.stdout and "xq_conv_bf16.hip" in r.stdout

@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv_bf16(const float *__restri
                 acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][q], ub[slot], zero, 0, 0, 0);
             } else if (nt == 3) {
                 // 20 accumulator tiles do not fit the 256 AGPRs: N-tile 3 is pinned to VGPRs (as in xq_conv.hip)
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[P][q]), "v"(ub[slot]));
+                // s_nop 1: a vector write of a source register must be 2 wait states ahead of an MFMA; the compiler pads its own MFMAs, it cannot
+                // see this one (tools/check_asm_mfma_hazards.py found a v_cvt_pk_bf16_f32 right in front of it)
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[q][nt]) : "v"(a[P][q]), "v"(ub[slot]));
             } else {
                 acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][q], ub[slot], acc[q][nt], 0, 0, 0);
             }
