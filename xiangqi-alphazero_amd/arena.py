@@ -16,10 +16,12 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 
-from . import engine, evaluator as ev_mod
+from . import engine, evaluator as ev_mod, hip
 from .sample_format import RESULT_DTYPE
 
 
@@ -53,27 +55,54 @@ def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_sim
     dense = None if sparse else torch.zeros((eval_games, 8100), dtype=torch.float32, device=dev)
     legal = torch.zeros((eval_games, 128), dtype=torch.float32, device=dev) if sparse else None
     value = torch.zeros(eval_games, dtype=torch.float32, device=dev)
+    zero = torch.zeros_like(eng.req_counts)
+
+    def step():
+        x = eng.select()
+        # the model that is SEARCHING evaluates every node of its search (root and leaves at any depth), so the
+        # choice follows the side to move of the real game, not of the evaluated position (train.py:479-483)
+        red_to_move = eng.slot_ints[:, 0] == 1
+        use_new = new_is_red == red_to_move
+        if sparse:
+            # No host round trip in a step: each model runs over the whole (small) slot batch with the OTHER model's
+            # request counts masked to zero -- xq_policy_head_legal skips those rows -- and the two results are merged
+            # on the device.  Batch size and conv variant are the same every step (no nonzero(), no data-dependent shapes).
+            ll_new, v_new = eval_new.evaluate_legal(x, eng.req_moves, torch.where(use_new, eng.req_counts, zero))
+            ll_old, v_old = eval_old.evaluate_legal(x, eng.req_moves, torch.where(use_new, zero, eng.req_counts))
+            torch.where(use_new.unsqueeze(1), ll_new, ll_old, out=legal)
+            torch.where(use_new, v_new.view(-1), v_old.view(-1), out=value)
+            eng.expand_legal(legal, value)
+        else:
+            _evaluate_subset(eng, eval_new, x, use_new.nonzero().view(-1), policy_is_probs, dense, legal, value)
+            _evaluate_subset(eng, eval_old, x, (~use_new).nonzero().view(-1), policy_is_probs, dense, legal, value)
+            eng.expand(dense, value, policy_is_probs)
+
+    # A sparse step is ~70 launches for a handful of games (eval_games = 10 in the reference's config): launch-bound.  It has no host
+    # synchronisation and no data-dependent shape, so it is recorded once into a HIP graph and replayed (same kernels, same results);
+    # XQ_ARENA_GRAPH=0 keeps it eager.  Only a capture-unsupported error keeps the eager path (as engine.capture_step).
+    graph = None
+    if sparse and os.environ.get("XQ_ARENA_GRAPH", "1") != "0":
+        step()
+        step()                                               # real steps: buffers of both evaluators exist before the recording
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                step()
+            graph = g
+        except hip.XqError:
+            raise
+        except RuntimeError as e:
+            msg = str(e).lower()
+            if not any(k in msg for k in ("captur", "hiperrorstreamcapture", "cudaerrorstreamcapture", "operation not permitted")):
+                raise
+            torch.cuda.synchronize(dev)
     while True:
         for _ in range(64):
-            x = eng.select()
-            # the model that is SEARCHING evaluates every node of its search (root and leaves at any depth), so the
-            # choice follows the side to move of the real game, not of the evaluated position (train.py:479-483)
-            red_to_move = eng.slot_ints[:, 0] == 1
-            use_new = new_is_red == red_to_move
-            if sparse:
-                # No host round trip in a step: each model runs over the whole (small) slot batch with the OTHER model's
-                # request counts masked to zero -- xq_policy_head_legal skips those rows -- and the two results are merged
-                # on the device.  Batch size and conv variant are the same every step (no nonzero(), no data-dependent shapes).
-                zero = torch.zeros_like(eng.req_counts)
-                ll_new, v_new = eval_new.evaluate_legal(x, eng.req_moves, torch.where(use_new, eng.req_counts, zero))
-                ll_old, v_old = eval_old.evaluate_legal(x, eng.req_moves, torch.where(use_new, zero, eng.req_counts))
-                torch.where(use_new.unsqueeze(1), ll_new, ll_old, out=legal)
-                torch.where(use_new, v_new.view(-1), v_old.view(-1), out=value)
-                eng.expand_legal(legal, value)
+            if graph is not None:
+                graph.replay()
             else:
-                _evaluate_subset(eng, eval_new, x, use_new.nonzero().view(-1), policy_is_probs, dense, legal, value)
-                _evaluate_subset(eng, eval_old, x, (~use_new).nonzero().view(-1), policy_is_probs, dense, legal, value)
-                eng.expand(dense, value, policy_is_probs)
+                step()
         st = eng.stats()
         if st["games_finished"] >= eval_games:
             break
