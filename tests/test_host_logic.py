@@ -387,3 +387,32 @@ def test_inline_asm_mfmas_keep_their_wait_states():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_mfma_hazards.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "xq_conv.hip" in r.stdout and "xq_train.hip" in r.stdout and "xq_conv_bf16.hip" in r.stdout
+
+
+def test_use_native_conv_leaves_the_cpu_path_and_the_state_dict_alone():
+    """XiangqiNet.use_native_conv(True) only re-routes CUDA tensors: on the CPU the module computes what it computed before (eval and
+    train mode; to float32 rounding -- torch picks other CPU convolution kernels for channels-last memory), its state_dict keeps keys, shapes and values, the tower filters stay plain [C, C, 3, 3]; unsupported widths
+    are refused; there is no CPU implementation behind native_conv (it raises off the GPU)."""
+    import copy
+    import torch
+    from xiangqi_alphazero_amd import hip, model, native_conv, weights
+    net = model.XiangqiNet(64, 2)
+    net.load_state_dict(weights.make_state_dict(64, 2, seed=2))
+    ref = copy.deepcopy(net)
+    net.use_native_conv(True)
+    assert all(b.native_conv for b in net.res_blocks) and not any(b.native_conv for b in ref.res_blocks)
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert a.shape == b.shape and torch.equal(a, b), k
+    assert net.res_blocks[0].conv1.weight.is_contiguous()
+    x = (torch.rand(5, 15, 10, 9, generator=torch.Generator().manual_seed(1)) < 0.1).float()
+    for mode in (False, True):
+        net.train(mode); ref.train(mode)
+        (la, va), (lb, vb) = net(x), ref(x)
+        assert torch.allclose(la, lb, rtol=0, atol=2e-5) and torch.allclose(va, vb, rtol=0, atol=2e-5)
+    with pytest.raises(ValueError):
+        model.XiangqiNet(16, 1).use_native_conv(True)
+    with pytest.raises(hip.XqError):
+        native_conv.conv3x3(torch.zeros(1, 64, 10, 9), torch.zeros(64, 64, 3, 3))
+    net.use_native_conv(False)
+    assert not any(b.native_conv for b in net.res_blocks)
