@@ -201,6 +201,9 @@ __global__ __launch_bounds__(256) void k_bn_dx(const float *__restrict__ DY, con
 // memory (NHWC: channels contiguous), one tile per half-wave, two steps in flight, transformed in registers; board edges are out-of-range buffer
 // offsets (zeros, no traffic).  No LDS and no barrier in the main loop.  Epilogue: the column half of G'^T . G' in registers, the row half
 // across the four waves through LDS, 9 values per channel pair into this split's partial; k_wgrad_reduce adds the splits in order.
+#ifndef XQ_WGRAD_STAGES
+#define XQ_WGRAD_STAGES 2
+#endif
 constexpr int WG_ESTR = 72;                                         // LDS row stride of the exchange (floats): half-waves 32 banks apart
 constexpr int WG_LDS_BYTES = 4 * 3 * 32 * WG_ESTR * 4;               // [p][s][32 rows][72] = 110 592
 
@@ -245,11 +248,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__
 
     // operands of TWO steps in flight (stage = step parity): one step of MFMAs (1 280 cycles) does not cover a loaded L2 / Infinity-Cache
     // round trip
-    float xa_[2][NT][5], xb_[2][NT][5], ya_[2][MT][3], yb_[2][MT][3];
-    int r15_[2];                                                     // tile-in-board (0..14) of the stage's NEXT issue, this lane's tile
-    unsigned bbase_[2];                                              // 90 * board of it
+    constexpr int NSTG = XQ_WGRAD_STAGES;
+    float xa_[NSTG][NT][5], xb_[NSTG][NT][5], ya_[NSTG][MT][3], yb_[NSTG][MT][3];
+    int r15_[NSTG];                                                     // tile-in-board (0..14) of the stage's NEXT issue, this lane's tile
+    unsigned bbase_[NSTG];                                              // 90 * board of it
 #pragma unroll
-    for (int sgi = 0; sgi < 2; ++sgi) {
+    for (int sgi = 0; sgi < NSTG; ++sgi) {
         const int tau0 = t_lo + 2 * sgi + kp, b0 = tau0 / 15;
         r15_[sgi] = tau0 - 15 * b0;
         bbase_[sgi] = 90u * (unsigned)b0;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__
         const int ty = (r * 11) >> 5, tx = r - 3 * ty;               // r / 3 for r < 32
         const unsigned pos0 = bb + (unsigned)(18 * ty + 3 * tx);
         const bool ok = tau < t_hi;
-        r += 4;
+        r += 2 * NSTG;
         if (r >= 15) {
             r -= 15;
             bb += 90u;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__
             g[mt][3] = __builtin_fmaf(2.0f, a1, __builtin_fmaf(4.0f, a2, a0));
             g[mt][4] = a2;
         }
-        issue(stage_tag, t + 4);                                    // this stage's registers are free: fetch the step after next (past the
+        issue(stage_tag, t + 2 * NSTG);                                    // this stage's registers are free: fetch the step after next (past the
                                                                     // range: out-of-range offsets, no traffic)
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -354,9 +358,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(const float *__restrict__
     };
     issue(std::integral_constant<int, 0>{}, t_lo);
     issue(std::integral_constant<int, 1>{}, t_lo + 2);
-    for (int t = t_lo; t < t_hi; t += 4) {                          // a step past t_hi multiplies zeros (every offset out of range)
+    if constexpr (NSTG == 3) issue(std::integral_constant<int, 2>{}, t_lo + 4);
+    for (int t = t_lo; t < t_hi; t += 2 * NSTG) {                   // a step past t_hi multiplies zeros (every offset out of range)
         step(std::integral_constant<int, 0>{}, t);
         step(std::integral_constant<int, 1>{}, t + 2);
+        if constexpr (NSTG == 3) step(std::integral_constant<int, 2>{}, t + 4);
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[4][3]));        // asm MFMA results -> VALU readers (invisible to the hazard recogniser)
 
