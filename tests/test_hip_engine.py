@@ -327,3 +327,27 @@ def test_mcts_shim_has_the_reference_call_shape(eng_mod):
     assert np.abs(pi - want).sum() <= 0.04
     a = m.get_action(game, temperature=0)
     assert pi[a] >= pi.max() - 0.02
+
+
+@pytest.mark.gpu
+def test_arena_graph_and_side_stream_change_nothing(monkeypatch):
+    """play_arena's sparse step replayed from a HIP graph with the old network on a forked stream (the shipped path) against the same
+    step launched eagerly on one stream: the same kernels on the same data, so every game ends with the same winner after the same
+    number of plies."""
+    import torch
+    from xiangqi_alphazero_amd import arena, evaluator, model, weights
+    nets = []
+    for seed in (1, 2):
+        n = model.XiangqiNet(64, 1)
+        n.load_state_dict(weights.make_state_dict(64, 1, seed=seed, policy_gain=4.0))
+        nets.append(n)
+    out = []
+    for graph, streams in (("1", "1"), ("0", "0"), ("1", "0")):
+        monkeypatch.setenv("XQ_ARENA_GRAPH", graph)
+        monkeypatch.setenv("XQ_ARENA_STREAMS", streams)
+        en, _ = evaluator.make_evaluator(nets[0], "cuda", "hip")
+        eo, _ = evaluator.make_evaluator(nets[1], "cuda", "hip")
+        res = arena.play_arena(en, eo, 6, 24, 60, device="cuda")
+        out.append([(int(r["winner"]), int(r["steps"])) for r in res])
+    assert out[0] == out[1] == out[2], out
+    assert len(out[0]) == 6 and all(s > 0 for _, s in out[0])

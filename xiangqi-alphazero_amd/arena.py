@@ -56,6 +56,8 @@ def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_sim
     legal = torch.zeros((eval_games, 128), dtype=torch.float32, device=dev) if sparse else None
     value = torch.zeros(eval_games, dtype=torch.float32, device=dev)
     zero = torch.zeros_like(eng.req_counts)
+    # XQ_ARENA_STREAMS=0: both networks on the one stream (A/B runs and the equality test)
+    side = torch.cuda.Stream(device=dev) if sparse and os.environ.get("XQ_ARENA_STREAMS", "1") != "0" else None
 
     def step():
         x = eng.select()
@@ -67,8 +69,20 @@ def play_arena(eval_new: Callable, eval_old: Callable, eval_games: int, eval_sim
             # No host round trip in a step: each model runs over the whole (small) slot batch with the OTHER model's
             # request counts masked to zero -- xq_policy_head_legal skips those rows -- and the two results are merged
             # on the device.  Batch size and conv variant are the same every step (no nonzero(), no data-dependent shapes).
-            ll_new, v_new = eval_new.evaluate_legal(x, eng.req_moves, torch.where(use_new, eng.req_counts, zero))
-            ll_old, v_old = eval_old.evaluate_legal(x, eng.req_moves, torch.where(use_new, zero, eng.req_counts))
+            # The two networks are independent: the old one runs on a side stream (forked from / joined to the main one), so at arena
+            # batch sizes -- ten games, every kernel a fraction of the chip -- the two towers overlap; recorded into the graph as two
+            # parallel branches.
+            c_new, c_old = torch.where(use_new, eng.req_counts, zero), torch.where(use_new, zero, eng.req_counts)
+            if side is not None:
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ll_old, v_old = eval_old.evaluate_legal(x, eng.req_moves, c_old)
+                ll_new, v_new = eval_new.evaluate_legal(x, eng.req_moves, c_new)
+                main.wait_stream(side)
+            else:
+                ll_new, v_new = eval_new.evaluate_legal(x, eng.req_moves, c_new)
+                ll_old, v_old = eval_old.evaluate_legal(x, eng.req_moves, c_old)
             torch.where(use_new.unsqueeze(1), ll_new, ll_old, out=legal)
             torch.where(use_new, v_new.view(-1), v_old.view(-1), out=value)
             eng.expand_legal(legal, value)
