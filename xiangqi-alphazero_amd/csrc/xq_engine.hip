@@ -238,7 +238,19 @@ __device__ __forceinline__ void wave_backup(int32_t *tN, double *tW, const int32
 // (thousands of byte reads of the LDS board per game), not HBM bound.
 constexpr int WAVES_PER_WG = 4;
 
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__restrict__ nn_in) {
+#ifndef XQ_SELECT_WAVES_PER_EU
+// Registers capped for three waves per SIMD (168 VGPRs, 47 spilled in the cold branches) instead of the 240 the compiler takes when
+// left alone (two waves): the descent and the leaf's move generation are latency / LDS-instruction bound, so resident games matter.
+// Measured on bench.py's two variants (select ms, near-uniform / peaked): 2 waves 0.177 / 0.364, 3 waves 0.135 / 0.350, 4 waves (94
+// spills) 0.159 / 0.328.  0 = the compiler's choice.
+#define XQ_SELECT_WAVES_PER_EU 3
+#endif
+#if XQ_SELECT_WAVES_PER_EU > 0
+#define XQ_SELECT_OCC __attribute__((amdgpu_waves_per_eu(XQ_SELECT_WAVES_PER_EU, XQ_SELECT_WAVES_PER_EU)))
+#else
+#define XQ_SELECT_OCC
+#endif
+__global__ __launch_bounds__(64 * WAVES_PER_WG) XQ_SELECT_OCC void k_select(Dev E, float *__restrict__ nn_in) {
     __shared__ SelectLds Ls[WAVES_PER_WG];
     SelectLds &L = Ls[threadIdx.x >> 6];
     const int slot = blockIdx.x * WAVES_PER_WG + (int)(threadIdx.x >> 6);
@@ -474,22 +486,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
         wave_sync();
         int side = g_side, mc = g_mc, nocap = g_nocap, node = 0, depth = 0;
         if (lane == 0) path[0] = 0;
+        // One dependent round trip to memory per level: every lane reads, with its candidate child's N / W / P, that child's own
+        // node words (children count + kind, first child, action) as well, so the winner's are already in a register when the arg-max
+        // is known -- the next level starts from a lane read instead of three more dependent loads (tM -> tC/tN -> ... -> tA).  The
+        // winner's N, read here, IS the next level's parent count.  Same values, same arithmetic, same order as before.
+        int m = __builtin_amdgcn_readfirstlane((int)tM[0]);
+        int first = __builtin_amdgcn_readfirstlane(tC[0]);
+        int pn = __builtin_amdgcn_readfirstlane(tN[0]);
         for (;;) {
-            const int m = __builtin_amdgcn_readfirstlane((int)tM[node]);
             const int nch = m & 0x3FFF, kind = m >> 14;
             if (nch == 0) break;
-            const int first = __builtin_amdgcn_readfirstlane(tC[node]);
-            const int pn = __builtin_amdgcn_readfirstlane(tN[node]);
             const double sqrtp = E.sqrt_tab[pn];
             const float sqrtp_f = (float)sqrtp, c_f = (float)E.cfg.c_puct;
             const double uni = 1.0 / (double)nch;
             double best = -INFINITY;
             int best_i = 0x7FFFFFFF;
+            int c_m = 0, c_first = 0, c_n = 0, c_a = 0;              // node words of this lane's best candidate
             for (int base = 0; base < nch; base += 64) {
                 const int i = base + lane;
                 if (i < nch) {
                     const int n = tN[first + i];
                     const double w = tW[first + i];
+                    const int cm = (int)tM[first + i], cf = tC[first + i], ca = (int)tA[first + i];
                     const double q = n ? w / (double)n : 0.0;
                     double ucb;
                     if (kind == 0) {
@@ -505,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
                         t = t / (double)(1 + n);
                         ucb = q + t;
                     }
-                    if (ucb > best) { best = ucb; best_i = i; }
+                    if (ucb > best) { best = ucb; best_i = i; c_m = cm; c_first = cf; c_n = n; c_a = ca; }
                 }
             }
 #pragma unroll
@@ -515,10 +533,30 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_select(Dev E, float *__re
                 if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
             }
             best_i = __builtin_amdgcn_readfirstlane(best_i);
-            if (best_i == 0x7FFFFFFF) { ovf |= 8; best_i = 0; }   // all-NaN scores: the reference would raise
+            int action;
+            if (best_i == 0x7FFFFFFF) {                              // all-NaN scores: the reference would raise
+                ovf |= 8; best_i = 0;
+                m = __builtin_amdgcn_readfirstlane((int)tM[first]);
+                pn = __builtin_amdgcn_readfirstlane(tN[first]);
+                action = __builtin_amdgcn_readfirstlane((int)tA[first]);
+                const int nf = __builtin_amdgcn_readfirstlane(tC[first]);
+                d_scan += (unsigned)nch;
+                const int child0 = first;
+                first = nf;
+                wave_make_move(L.board, L.hist, action, side, mc, nocap);
+                depth += 1;
+                if (depth >= E.path_cap) { ovf |= 16; depth = E.path_cap - 1; }
+                if (lane == 0) path[depth] = child0;
+                node = child0;
+                continue;
+            }
             d_scan += (unsigned)nch;
             const int child = first + best_i;
-            const int action = __builtin_amdgcn_readfirstlane((int)tA[child]);
+            const int src = best_i & 63;                              // child i was lane i % 64's candidate, and its best (it won)
+            action = __builtin_amdgcn_readlane(c_a, src);
+            m = __builtin_amdgcn_readlane(c_m, src);
+            pn = __builtin_amdgcn_readlane(c_n, src);
+            first = __builtin_amdgcn_readlane(c_first, src);
             wave_make_move(L.board, L.hist, action, side, mc, nocap);
             depth += 1;
             if (depth >= E.path_cap) { ovf |= 16; depth = E.path_cap - 1; }
