@@ -239,11 +239,11 @@ __device__ __forceinline__ void wave_backup(int32_t *tN, double *tW, const int32
 constexpr int WAVES_PER_WG = 4;
 
 #ifndef XQ_SELECT_WAVES_PER_EU
-// Registers capped for three waves per SIMD (168 VGPRs, 47 spilled in the cold branches) instead of the 240 the compiler takes when
-// left alone (two waves): the descent and the leaf's move generation are latency / LDS-instruction bound, so resident games matter.
-// Measured on bench.py's two variants (select ms, near-uniform / peaked): 2 waves 0.177 / 0.364, 3 waves 0.135 / 0.350, 4 waves (94
-// spills) 0.159 / 0.328.  0 = the compiler's choice.
-#define XQ_SELECT_WAVES_PER_EU 3
+// 0 = the compiler's choice (240 VGPRs, two waves per SIMD, no spills) -- the shipped setting.  Capping the registers for three / four
+// waves per SIMD (168 / 128 VGPRs) was measured: select 0.135 / 0.159 ms instead of 0.177 (near-uniform) and 0.350 / 0.328 instead of 0.364
+// (peaked), but the 47 / 94 spilled registers are stored by EVERY wave (12 KB of scratch per game): k_select's HBM-side writes went from
+// 47 MB to 146 MB per launch (TCC_EA0_WRREQ).  0.04 ms of a 50 ms step is not worth tripling the kernel's traffic.
+#define XQ_SELECT_WAVES_PER_EU 0
 #endif
 #if XQ_SELECT_WAVES_PER_EU > 0
 #define XQ_SELECT_OCC __attribute__((amdgpu_waves_per_eu(XQ_SELECT_WAVES_PER_EU, XQ_SELECT_WAVES_PER_EU)))
