@@ -12,6 +12,7 @@
 // forward 3 passes (+1 with a residual), backward 7 (+1), of rows * C * 4 bytes.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "xq_common.h"
 
@@ -209,6 +210,12 @@ constexpr int WG_ESTR = 72;                                         // LDS row s
 constexpr int WG_LDS_BYTES = 4 * 3 * 32 * WG_ESTR * 4;               // [p][s][32 rows][72] = 110 592
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// f(integral_constant<int, 0>), f(integral_constant<int, 1>), ... : a compile-time unrolled loop whose index is a constant expression
+template <int... I, class F>
+__device__ __forceinline__ void for_seq(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 // Epilogue of the weight-gradient kernels: dW[r][s] = sum_p G_r'[p][r] sum_j G_c'[j][s] acc[j] -- column half in registers, row half across the
 // four waves through LDS -- 9 values per channel pair into this split's partial.
@@ -590,6 +597,64 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad_lds(const float *__restri
         }
     };
 
+    // One step, hand-interleaved (MT = 4): behind each of the 20 MFMAs of step t (from vg[S]) goes one slice of the transform of step t + 1
+    // (LDS buffer `buf` -> vg[D]); an LDS read is issued one slice before its first use.  One wave per SIMD executes in order: a transform
+    // in FRONT of the MFMAs costs its full dependent-chain latency (~8 cycles per instruction, nothing to hide it), behind an MFMA it costs
+    // ~5 cycles of a pipe that is busy 64.  sched_barrier(0) pins the order.
+    auto fused_step = [&](auto src_tag, auto dst_tag, int buf) __attribute__((always_inline)) {
+        constexpr int S = decltype(src_tag)::value, D = decltype(dst_tag)::value;
+        if constexpr (MT != 4) {
+            transform(dst_tag, buf);
+            mfmas(src_tag);
+        } else {
+            const char *bb = lds + buf * BUF;
+            const char *ya_p = p == 3 ? lds + ZERO + ry_lane : bb + ry_a, *yb_p = p == 0 ? lds + ZERO + ry_lane : bb + ry_b;
+            float xa[5], xb[5], w[5], tt = 0.0f, a[4][3];
+            f32x4 qa[3], qb[3];
+            auto rdx = [&](int c) __attribute__((always_inline)) {
+                xa[c] = *(const float *)(bb + rx_a + c * BCI * 4);
+                xb[c] = *(const float *)(bb + rx_b + c * BCI * 4);
+            };
+            auto rdy = [&](int c) __attribute__((always_inline)) {
+                qa[c] = *(const f32x4 *)(ya_p + (p == 3 ? c * 512 : c * BCO * 4));
+                qb[c] = *(const f32x4 *)(yb_p + (p == 0 ? c * 512 : c * BCO * 4));
+            };
+            rdx(0); rdx(1);
+            for_seq(std::make_integer_sequence<int, 20>{}, [&](auto i_tag) __attribute__((always_inline)) {
+                constexpr int I = decltype(i_tag)::value;
+                constexpr int j = I / 4, fo = I % 4;
+                constexpr int f = (fo + 3) & 3;                       // the inline-asm MFMA first of its group, with its own wait states
+                if (f == 3)
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j][f]) : "v"(gg[S][f][j]), "v"(vv[S][0][j]));
+                else
+                    acc[j][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg[S][f][j], vv[S][0][j], acc[j][f], 0, 0, 0);
+                if constexpr (I == 0) { rdx(2); rdx(3); }
+                if constexpr (I == 1) { w[0] = __builtin_fmaf(sg, xb[0], xa[0]); w[1] = __builtin_fmaf(sg, xb[1], xa[1]); rdx(4); }
+                if constexpr (I == 2) { w[2] = __builtin_fmaf(sg, xb[2], xa[2]); w[3] = __builtin_fmaf(sg, xb[3], xa[3]); rdy(0); }
+                if constexpr (I == 3) { w[4] = __builtin_fmaf(sg, xb[4], xa[4]); tt = w[3] - w[1]; rdy(1); }
+                if constexpr (I == 4) { vv[D][0][0] = __builtin_fmaf(2.0f, w[0] - w[2], tt); vv[D][0][3] = tt; rdy(2); }
+                if constexpr (I == 5) vv[D][0][1] = __builtin_fmaf(2.0f, w[1], -w[3]) + w[2];
+                if constexpr (I == 6) vv[D][0][2] = 3.0f * w[2] - __builtin_fmaf(2.0f, w[1], w[3]);
+                if constexpr (I == 7) vv[D][0][4] = __builtin_fmaf(-2.0f, tt, w[4] - w[2]);
+                if constexpr (I >= 8 && I <= 10) {
+                    constexpr int c = I - 8;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a[mt][c] = __builtin_fmaf(sg, qb[c][mt], qa[c][mt]);
+                }
+                if constexpr (I >= 11 && I <= 14) {
+                    constexpr int mt = I - 11;
+                    const float s02 = a[mt][0] + a[mt][2];
+                    gg[D][mt][0] = a[mt][0];
+                    gg[D][mt][1] = s02 + a[mt][1];
+                    gg[D][mt][2] = s02 - a[mt][1];
+                    gg[D][mt][3] = __builtin_fmaf(2.0f, a[mt][1], __builtin_fmaf(4.0f, a[mt][2], a[mt][0]));
+                    gg[D][mt][4] = a[mt][2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    };
+
     // step t's operands: fetched (global -> registers) during step t - 4 / t - 3, stashed into LDS buffer t & 1 during step t - 2,
     // transformed during step t - 1, multiplied in step t
     fetch(std::integral_constant<int, 0>{}, t_lo);
@@ -605,13 +670,13 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad_lds(const float *__restri
     for (int t = t_lo; t < t_hi; t += 2) {
         stash(std::integral_constant<int, 0>{}, 0);                  // step t + 2 -> buffer 0
         fetch(std::integral_constant<int, 0>{}, t + 4);
-        transform(std::integral_constant<int, 1>{}, 1);              // step t + 1 (buffer 1) -> vg[1], beside ...
-        mfmas(std::integral_constant<int, 0>{});                     // ... step t's MFMAs from vg[0]
+        __builtin_amdgcn_sched_barrier(0);
+        fused_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 1);   // step t's MFMAs from vg[0]; step t + 1 (buffer 1) -> vg[1]
         __syncthreads();
         stash(std::integral_constant<int, 1>{}, 1);                  // step t + 3 -> buffer 1
         fetch(std::integral_constant<int, 1>{}, t + 5);
-        transform(std::integral_constant<int, 0>{}, 0);              // step t + 2 (buffer 0) -> vg[0]
-        mfmas(std::integral_constant<int, 1>{});                     // step t + 1 (zeros past t_hi: its loads were out of range)
+        __builtin_amdgcn_sched_barrier(0);
+        fused_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 0);   // step t + 1 from vg[1]; step t + 2 (buffer 0) -> vg[0]
         __syncthreads();
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[4][3]));
