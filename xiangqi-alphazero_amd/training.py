@@ -143,7 +143,7 @@ def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shu
                           % dist.get_world_size(group))
     # the two losses of every batch are added up ON THE DEVICE in float64 (the same additions, in the same order, as the reference's
     # Python floats, train.py:421-423) and read once at the end: no host synchronisation inside the epoch loop
-    totals = torch.zeros(2, dtype=torch.float64, device=buffer.device)
+    totals = None                                                      # float64[2] on the losses' device
     batches = 0
     for _ in range(config.num_epochs):
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
@@ -172,10 +172,10 @@ def train_network(model, optimizer, scheduler, buffer: ReplayBuffer, config, shu
             pv = torch.stack([policy_loss.detach(), value_loss.detach()])
             if use_ddp and full >= world:
                 dist.all_reduce(pv, group=group)                       # the slices' shares add up to the batch's losses
-            totals += pv.double()
+            totals = pv.double() if totals is None else totals + pv.double()
             batches += 1
     scheduler.step()
-    total_p, total_v = totals.tolist()
+    total_p, total_v = totals.tolist() if totals is not None else (0.0, 0.0)
     return {"policy_loss": total_p / max(batches, 1), "value_loss": total_v / max(batches, 1),
             "total_loss": (total_p + total_v) / max(batches, 1), "learning_rate": optimizer.param_groups[0]["lr"]}
 
