@@ -363,8 +363,23 @@ def complete_games_leg(args, dev, rank, world, dist, backend):
             "mean_plies_per_game": round(sum(p[3] for p in parts) / max(n_games, 1), 2),
             "launch": st.get("launch"), "slot_policy": "games_target = games: finished slots idle until the last game ends (tail-limited; "
                                                        "the refilling figure is tools/measure_games_per_hour.py --refill)",
+            "refilling_engine": refill_reference(),
             "rank0": {"plies_p10": int(np.percentile(steps, 10)), "plies_p90": int(np.percentile(steps, 90)),
                       "red_wins": st["red_wins"], "black_wins": st["black_wins"], "draws": st["draws"], "samples": int(len(samples))}}
+
+
+def refill_reference():
+    """The steady-state figure of the same configuration with refilling slots, from the committed run of
+    tools/measure_games_per_hour.py --refill (230 s of warm-up + 150 s: several game lengths, too long for a bench run).  NOT measured in
+    this run, and labelled so."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_games_per_hour_refill_cfg1_1024slots_400sims_128x6.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return {"measured_in_this_run": False, "source": "profiles/" + os.path.basename(path), "games_per_hour": d["games_per_hour"],
+                "simulations_per_s": d["simulations_per_s"], "per": "one GPU, 1024 slots, every finished slot starts a new game at once"}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def rehearse(args, rank, world, dist):
