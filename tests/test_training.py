@@ -66,6 +66,10 @@ def test_device_filter_transform_equals_the_host_transform(channels, co_block):
         # float64 sums of three products taken in a different order may round differently in the last float32 bit
         assert (dev - host).abs().max().item() <= 1.2e-7 * host.abs().max().item()
         assert (dev != host).double().mean().item() < 1e-3
+    both = hip.wino_transform_filters_device(w, co_block, both=True)                 # one launch: [0] forward, [1] data gradient
+    assert both.shape == (2,) + host.shape
+    assert torch.equal(both[0], hip.wino_transform_filters_device(w, co_block, False))
+    assert torch.equal(both[1], hip.wino_transform_filters_device(w, co_block, True))
 
 
 @pytest.mark.gpu
